@@ -1,0 +1,64 @@
+"""Shared helpers for the tests: fixture access and config construction."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+TREE_FIELDS = ['node_visits', 'node_values', 'node_raw_values', 'parents', 'action_from_parent',
+               'children_index', 'children_prior_logits', 'children_visits', 'children_rewards',
+               'children_values', 'to_play']
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def make_config(gumbel, A, S, players, gamma, alpha=0.25, c_visit=50, c_scale=1.0, m=16):
+    return SimpleNamespace(simulations=int(S), n_actions=int(A), gamma=float(gamma) if gamma != 1 else 1,
+                           players=int(players), gumbel=bool(gumbel), max_considered_actions=m,
+                           gumbel_scale=1.0, c_visit=c_visit, c_scale=c_scale, c_base=19625, c_init=1.25,
+                           dirichlet_alpha=alpha, exploration_frac=0.25)
+
+
+class HashCase:
+    """One case of search_hash_{puct,gumbel}.npz / search_stream_puct.npz."""
+
+    def __init__(self, z, prefix):
+        self.z, self.p = z, prefix
+        m = z[prefix + 'meta']
+        (self.gumbel, self.A, self.S, self.players, self.H, self.to_play, self.parent_predicts,
+         self.logit_shift, self.reward_on, self.seed, self.idx, self.root_code, self.calls) = [int(x) for x in m]
+        self.gamma = float(z[prefix + 'gamma'])
+        alpha = float(z[prefix + 'alpha']) if (prefix + 'alpha') in z else 0.25
+        self.cfg = make_config(self.gumbel, self.A, self.S, self.players, self.gamma, alpha=alpha)
+
+    def __getitem__(self, k):
+        return self.z[self.p + k]
+
+    def has(self, k):
+        return (self.p + k) in self.z
+
+
+def hash_cases(name, prefix='c'):
+    z = load(name)
+    return [HashCase(z, f'{prefix}{i}_') for i in range(int(z['n_cases']))]
+
+
+def assert_tree_equal(got, case, fields=TREE_FIELDS, hidden=True):
+    """Bit-exact comparison of every reference Tree field."""
+    for f in fields:
+        ref = case[f]
+        val = np.asarray(getattr(got, f))
+        assert val.shape == ref.shape or val.reshape(ref.shape).shape == ref.shape, (f, val.shape, ref.shape)
+        val = val.reshape(ref.shape)
+        assert val.dtype == ref.dtype, (f, val.dtype, ref.dtype)
+        if not np.array_equal(val, ref):
+            bad = np.argwhere(val != ref)
+            raise AssertionError(f'{f}: {len(bad)} mismatches, first at {bad[0]}: '
+                                 f'{val[tuple(bad[0])]!r} vs {ref[tuple(bad[0])]!r}')
+    if hidden:
+        ref = case['hidden_states']
+        val = np.asarray(got.hidden_states).reshape(ref.shape)
+        assert np.array_equal(val, ref), 'hidden_states'
