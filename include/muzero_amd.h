@@ -1,0 +1,163 @@
+/*
+ * muzero_amd.h -- C ABI of the MI355X (gfx950) batched MuZero search engine.
+ *
+ * Shared library: muzero_amd/libmuzero_amd.so.  Plain pointers and sizes only.
+ * Unless a parameter is suffixed _h, pointers are DEVICE pointers and the work
+ * is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ * Every call returns 0 on success and a negative code on error; the message
+ * for the calling thread's last error is mz_last_error().
+ *
+ * Each entry point names the reference code (trunghng/muzero, path:line) whose
+ * behaviour it replaces for a batch of B independent trees.
+ */
+#ifndef MUZERO_AMD_H
+#define MUZERO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_OK 0
+#define MZ_ERR_ARG (-1)      /* invalid argument / shape */
+#define MZ_ERR_HIP (-2)      /* HIP runtime failure */
+#define MZ_ERR_STATE (-3)    /* call out of order (e.g. expand before select) */
+#define MZ_ERR_DEVICE (-4)   /* a kernel flagged an internal inconsistency */
+
+#define MZ_MAX_ACTIONS 64
+
+/* How the per-selection tie-break uniforms of PUCT (mcts/action_selection.py:46) are supplied. */
+#define MZ_NOISE_COUNTER 0   /* u = f(seed, tree id, call index, action); see csrc/noise.h */
+#define MZ_NOISE_BUFFER 1    /* u = noise[tree][call][action] from a caller buffer */
+#define MZ_NOISE_NONE 2      /* u = 0 */
+
+/* Built-in leaf evaluators for the fused search (mz_search_run). */
+#define MZ_NET_HASH 0        /* synthetic hash network (csrc/hashnet.h) */
+#define MZ_NET_MLP 1         /* MuZeroFullyConnectedNetwork, network.py:189-225,405-479 */
+
+/* The attributes MCTS reads from its config (mcts/mcts.py:27-30,68-69,90,112,162,181-227,236). */
+typedef struct mz_config {
+    int32_t n_actions;              /* config.n_actions, 1..64 */
+    int32_t n_simulations;          /* config.simulations */
+    int32_t players;                /* config.players, 1 or 2 */
+    int32_t gumbel;                 /* config.gumbel */
+    int32_t hidden_size;            /* floats per hidden state (product of its dims) */
+    int32_t max_batch;              /* trees the context is sized for */
+    double discount;                /* config.gamma */
+    double c_base, c_init;          /* PUCT */
+    int32_t max_considered_actions; /* Gumbel */
+    int32_t noise_mode;             /* MZ_NOISE_* (PUCT only) */
+    double c_visit, c_scale;        /* Gumbel */
+    uint64_t seed;                  /* MZ_NOISE_COUNTER key */
+    const double *c_table_h;        /* optional host table [n_simulations+2] of
+                                       c_init + log((n + c_base + 1)/c_base) as the caller's libm/NumPy
+                                       evaluates it; NULL = computed with the C library's log() */
+    int32_t device;                 /* HIP device ordinal */
+    int32_t lanes_per_tree;         /* 0 = choose; else a power of two >= n_actions, <= 64 */
+} mz_config;
+
+typedef struct mz_ctx mz_ctx;
+
+/* Host views of one tree, field for field the reference's Tree (mcts/tree.py:26-40).
+ * All pointers are HOST buffers sized for N = n_simulations + 1 nodes. */
+typedef struct mz_tree_host {
+    int32_t *node_visits;        /* [N] */
+    double *node_values;         /* [N] */
+    double *node_raw_values;     /* [N] */
+    int32_t *parents;            /* [N] */
+    int32_t *action_from_parent; /* [N] */
+    int32_t *to_play;            /* [N] */
+    int32_t *children_index;     /* [N][A] */
+    void *children_prior_logits; /* [N][A] double (PUCT) or float (Gumbel) */
+    int32_t *children_visits;    /* [N][A] */
+    double *children_rewards;    /* [N][A] */
+    double *children_values;     /* [N][A] */
+    float *hidden_states;        /* [N][H], may be NULL */
+} mz_tree_host;
+
+/* Replaces MCTS.__init__ (mcts/mcts.py:19-20) + the array allocation of
+ * initialize_tree (mcts/mcts.py:68-92): allocates the tree storage for max_batch trees once. */
+mz_ctx *mz_create(const mz_config *cfg);
+void mz_destroy(mz_ctx *ctx);
+const char *mz_last_error(void);
+
+/* Replaces add_exploration_noise (mcts/mcts.py:22-31) + mask_illegal_action_logits
+ * (utils/game_utils.py:71-78) for B roots.  logits f32[B][A]; dirichlet f64[B][A] (PUCT) or NULL
+ * (Gumbel); legal u8[B][A]; out_prior f64[B][A] (PUCT) / f32[B][A] (Gumbel). */
+int mz_root_prepare(mz_ctx *ctx, int32_t B, const float *logits, const double *dirichlet,
+                    double exploration_frac, const uint8_t *legal, void *out_prior, void *stream);
+
+/* Replaces initialize_tree's root update (mcts/mcts.py:93-96, update_tree_node :37-57).
+ * root_prior: prepared prior logits, f64[B][A] (PUCT) or f32[B][A] (Gumbel); root_value f64[B];
+ * root_hidden f32[B][H] or NULL; root_to_play i32[B]; legal u8[B][A]; gumbel f64[B][A] (Gumbel only).
+ * tree_id0: id of tree 0 for counter noise (a rank passes its first global tree index). */
+int mz_tree_reset(mz_ctx *ctx, int32_t B, const void *root_prior, const double *root_value,
+                  const float *root_hidden, const int32_t *root_to_play, const uint8_t *legal,
+                  const double *gumbel, uint64_t tree_id0, void *stream);
+
+/* Replaces MCTS.simulate (mcts/mcts.py:98-114) with the selection rules of
+ * mcts/action_selection.py:25-49 (PUCT) / :73-118 (Gumbel root + interior) and the value
+ * transforms of mcts/qtransforms.py, for every tree.  noise: f64[B][max_calls][A] when
+ * noise_mode is MZ_NOISE_BUFFER, else NULL.  If out_parent_hidden (f32[B][H]) is not NULL it
+ * receives hidden_states[parent], the input of recurrent_inference (mcts/mcts.py:241);
+ * out_parent / out_action (i32[B], optional) receive the selected (node, action) pairs. */
+int mz_select(mz_ctx *ctx, const double *noise, int32_t noise_max_calls, float *out_parent_hidden,
+              int32_t *out_parent, int32_t *out_action, void *stream);
+
+/* Device arrays written by the last mz_select: i32[B] each (parent node, action, next_to_play, depth). */
+int mz_select_outputs(mz_ctx *ctx, const int32_t **parent, const int32_t **action,
+                      const int32_t **next_to_play, const int32_t **depth);
+
+/* Replaces MCTS.expand + MCTS.backward (mcts/mcts.py:116-164) for the leaf each tree selected.
+ * logits f32[B][A], value f64[B], reward f64[B], next_hidden f32[B][H] (or NULL). */
+int mz_expand_backup(mz_ctx *ctx, const float *logits, const double *value, const double *reward,
+                     const float *next_hidden, void *stream);
+
+/* Replaces muzero_action_selection_to_act / gumbel_muzero_action_selection_to_act
+ * (mcts/action_selection.py:52-70, :121-138) and the return of MCTS.search (mcts/mcts.py:249-252).
+ * u f64[B]: the uniform behind np.random.choice (PUCT; NULL = 0).  Outputs: action i32[B],
+ * probs f64[B][A], root_value f64[B], q f64[B][A] (may be NULL). */
+int mz_to_act(mz_ctx *ctx, double temperature, const double *u, int32_t *out_action,
+              double *out_probs, double *out_root_value, double *out_q, void *stream);
+
+/* Fused search: all n_simulations of mcts/mcts.py:236-248 in one launch, leaves evaluated by a
+ * built-in network.  net_kind MZ_NET_HASH: params = {logit_shift, reward_on, parent_predicts}
+ * (host int32[3]).  Tree must have been reset. */
+int mz_search_run(mz_ctx *ctx, int32_t net_kind, const void *net_params_h, const double *noise,
+                  int32_t noise_max_calls, void *stream);
+
+/* Copies tree b to host arrays (synchronises `stream`).  Nodes not yet expanded read as a fresh
+ * tree's (mcts/mcts.py:72-92). */
+int mz_tree_export(mz_ctx *ctx, int32_t b, mz_tree_host *out_h, void *stream);
+
+/* Per-tree counters since the last reset: node_visits i64[B] = sum(node_visits) - 1
+ * (device or NULL), noise_calls i32[B] (device or NULL). */
+int mz_stats(mz_ctx *ctx, int64_t *out_node_visits, int32_t *out_noise_calls, void *stream);
+
+/* Per-node entry points behind the reference's module-level functions.  They evaluate ONE rule at
+ * node `node` of tree `b` of the context and copy the result to host.
+ * which: 0 qtransform_by_parent_and_siblings (mcts/qtransforms.py:7-22)
+ *        1 qtransform_completed_by_mix_value (mcts/qtransforms.py:25-48)
+ *        2 compute_mixed_value vector        (mcts/qtransforms.py:51-77)
+ * out_h f64[A]. */
+int mz_node_qtransform(mz_ctx *ctx, int32_t b, int32_t node, int32_t which, double *out_h, void *stream);
+/* Selection at one node: depth 0 = root rule, else interior (mcts/action_selection.py:11-22);
+ * uniform_h f64[A] or NULL (PUCT tie-break draw).  Returns the action in *out_action_h. */
+int mz_node_select(mz_ctx *ctx, int32_t b, int32_t node, int32_t depth, const double *uniform_h,
+                   int32_t *out_action_h, void *stream);
+/* Uploads host arrays as tree b (inverse of mz_tree_export); root_legal_h f64[A], gumbel_h f64[A] or NULL. */
+int mz_tree_import(mz_ctx *ctx, int32_t b, const mz_tree_host *in_h, const double *root_legal_h,
+                   const double *gumbel_h, void *stream);
+
+/* Sequential-halving schedule, mcts/action_selection.py:160-175 (host, pure integer). out_h i32[S]. */
+int mz_considered_visits(int32_t max_considered_actions, int32_t simulations, int32_t *out_h);
+
+/* Library/ABI version. */
+int mz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUZERO_AMD_H */

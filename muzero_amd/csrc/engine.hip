@@ -1,0 +1,731 @@
+// Kernels and C ABI of the batched search engine (gfx950).  See include/muzero_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/muzero_amd.h"
+#include "tree_ops.h"
+
+using namespace mz;
+
+// ============================================================================ kernels
+
+#define MZ_BLOCK 256
+
+template <int LANES>
+__device__ __forceinline__ bool group_ids(const Dev &d, int *t, int *a)
+{
+    int gid = (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / LANES);
+    *t = gid;
+    *a = threadIdx.x % LANES;
+    return gid < d.B;
+}
+
+// Root rows + per-tree search state (mcts/mcts.py:93-96 on top of the lazily initialised storage).
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_reset(Dev d, const void *root_prior, const double *root_value,
+                                                     const float *root_hidden, const int32_t *root_to_play,
+                                                     const uint8_t *legal, const double *gumbel,
+                                                     int max_considered)
+{
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    const int A = d.L.A;
+    bool on = a < A;
+    RowView w = view(d, t, 0);
+    double val = root_value[t];
+    if (a == 0) {
+        NodeHdr h;
+        h.visits = 1; h.parent = -1; h.afp = -1; h.to_play = root_to_play[t]; h.value = val; h.raw = val;
+        *w.hdr = h;
+        d.noise_calls[t] = 0;
+        d.visit_total[t] = 0;
+        d.sel_depth[t] = -1;
+    }
+    bool lg = on && legal[(long long)t * A + a] != 0;
+    unsigned long long mask = __ballot(lg);
+    int sh = (int)((threadIdx.x % 64) / LANES) * LANES;  // this group's lanes inside the 64-bit ballot
+    mask = LANES == 64 ? mask : (mask >> sh) & ((1ull << LANES) - 1ull);
+    if (on) {
+        w.cval[a] = 0.0; w.crew[a] = 0.0; w.cvis[a] = 0; w.cidx[a] = -1;
+        if (GUMBEL) {
+            reinterpret_cast<float *>(w.prior)[a] = reinterpret_cast<const float *>(root_prior)[(long long)t * A + a];
+            d.gumbel[(long long)t * A + a] = gumbel[(long long)t * A + a];
+        } else {
+            reinterpret_cast<double *>(w.prior)[a] = reinterpret_cast<const double *>(root_prior)[(long long)t * A + a];
+        }
+    }
+    if (a == 0) {
+        d.legal[t] = mask;
+        int n_legal = __popcll(mask);
+        d.m_considered[t] = max_considered < n_legal ? max_considered : n_legal;
+    }
+    if (root_hidden) {
+        float *dst = d.hidden + (long long)t * d.L.N * d.L.H;
+        for (int i = a; i < d.L.H; i += LANES) dst[i] = root_hidden[(long long)t * d.L.H + i];
+    }
+}
+
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_select(Dev d, const double *noise, int noise_max_calls,
+                                                      float *out_parent_hidden, int32_t *out_parent,
+                                                      int32_t *out_action)
+{
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    bool on = a < d.L.A;
+    const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
+    int action, ntp, depth;
+    int parent = descend<LANES, GUMBEL>(d, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+    if (a == 0) {
+        d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
+        if (out_parent) out_parent[t] = parent;
+        if (out_action) out_action[t] = action;
+    }
+    if (out_parent_hidden) {
+        const float *src = d.hidden + ((long long)t * d.L.N + parent) * d.L.H;
+        for (int i = a; i < d.L.H; i += LANES) out_parent_hidden[(long long)t * d.L.H + i] = src[i];
+    }
+}
+
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_expand_backup(Dev d, int leaf, const float *logits,
+                                                             const double *value, const double *reward,
+                                                             const float *next_hidden)
+{
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    bool on = a < d.L.A;
+    int parent = d.sel_parent[t], action = d.sel_action[t], ntp = d.sel_ntp[t], depth = d.sel_depth[t];
+    if (depth < 1 || depth > d.L.S || parent < 0 || parent >= leaf) {  // select did not run for this leaf
+        if (a == 0) atomicExch(d.err, 1);
+        return;
+    }
+    float lg = on ? logits[(long long)t * d.L.A + a] : 0.0f;
+    expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t]);
+    if (next_hidden) {
+        float *dst = d.hidden + ((long long)t * d.L.N + leaf) * d.L.H;
+        for (int i = a; i < d.L.H; i += LANES) dst[i] = next_hidden[(long long)t * d.L.H + i];
+    }
+    if (a == 0) d.sel_depth[t] = -1;
+}
+
+// Whole search in one launch with the synthetic hash network as the leaf evaluator.
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int first_leaf, int n_sims,
+                                                           const double *noise, int noise_max_calls)
+{
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    const int A = d.L.A, H = d.L.H;
+    bool on = a < A;
+    const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
+    float *hid = d.hidden + (long long)t * d.L.N * H;
+    for (int s = 0; s < n_sims; s++) {
+        int leaf = first_leaf + s;
+        int action, ntp, depth;
+        int parent = descend<LANES, GUMBEL>(d, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+        const float *ph = hid + (long long)parent * H;
+        uint32_t pcode = (uint32_t)ph[0] | ((uint32_t)ph[1] << 16);
+        uint32_t ccode = hash2(pcode, 300 + action);
+        uint32_t src = hn.parent_predicts ? pcode : ccode;
+        float lg = on ? hash_logit(src, a, hn.logit_shift) : 0.0f;
+        expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, hash_value(src),
+                                     hash_reward(ccode, hn.reward_on));
+        float *dst = hid + (long long)leaf * H;
+        for (int i = a; i < H; i += LANES) dst[i] = hash_hidden(ccode, i);
+        __threadfence_block();  // this group's stores are read by its other lanes in the next descent
+    }
+}
+
+// mcts/action_selection.py:52-70 (PUCT) / :121-138 (Gumbel) + mcts/tree.py:60-68.
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, const double *u,
+                                                      int32_t *out_action, double *out_probs,
+                                                      double *out_root_value, double *out_q)
+{
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    const int A = d.L.A;
+    bool on = a < A;
+    const double inf = __builtin_huge_val();
+    NodeStats s = load_node<GUMBEL>(d, t, 0, a, on);
+    bool legal = (d.legal[t] >> a) & 1ull;
+    int action;
+    double prob, qout;
+    if constexpr (!GUMBEL) {
+        int total = gsumi<LANES>(on ? s.cv : 0);
+        int den = total > 1 ? total : 1;
+        double vp = total > 0 ? (double)s.cv / (double)den : 1.0 / (double)A;
+        const double tiny = 2.2250738585072014e-308;
+        double lg = log(vp > tiny ? vp : tiny);
+        double mx = gmax<LANES>(on ? lg : -inf);
+        double tt = temperature > 1e-27 ? temperature : 1e-27;
+        lg = (lg - mx) / tt;
+        double e = on ? exp(lg) : 0.0;
+        double es = gsum_np<LANES, double>(e, a, A);
+        prob = e / es;
+        // legacy np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
+        double acc = 0.0, mine = 0.0;
+        for (int i = 0; i < A; i++) { acc += gshfl<LANES>(prob, i); if (a == i) mine = acc; }
+        mine = mine / acc;
+        double uu = u ? u[t] : 0.0;
+        int idx = gsumi<LANES>((on && mine <= uu) ? 1 : 0);
+        action = idx < A ? idx : A - 1;
+        qout = s.r + d.discount * s.v;
+    } else {
+        int vsum;
+        double cq = qt_completed_mix<LANES>(d, s, a, on, &vsum);
+        int considered = gmaxi<LANES>(on ? s.cv : -2147483647);
+        double sc = gumbel_score<LANES>(s, on, on ? d.gumbel[(long long)t * A + a] : 0.0, cq, considered);
+        if (!on || !legal) sc = -inf;
+        action = gargmax<LANES>(sc, on ? a : 0x7fffffff);
+        double x = s.prior + cq;
+        double mx = gmax<LANES>(on ? x : -inf);
+        x = legal ? x - mx : -1.7976931348623157e308;
+        double e = on ? exp(x) : 0.0;
+        double es = gsum_np<LANES, double>(e, a, A);
+        prob = e / es;
+        qout = cq;
+    }
+    if (on) {
+        out_probs[(long long)t * A + a] = prob;
+        if (out_q) out_q[(long long)t * A + a] = qout;
+    }
+    if (a == 0) { out_action[t] = action; out_root_value[t] = s.nval; }
+}
+
+// mcts/mcts.py:22-31 + utils/game_utils.py:71-78.
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const float *logits,
+                                                            const double *dirichlet, double frac,
+                                                            const uint8_t *legal, void *out)
+{
+    int gid = (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / LANES), a = threadIdx.x % LANES;
+    if (gid >= B) return;
+    bool on = a < A;
+    long long k = (long long)gid * A + a;
+    float lg = on ? logits[k] : 0.0f;
+    bool lgl = on && legal[k] != 0;
+    if constexpr (GUMBEL) {
+        float mx = gmaxf<LANES>(on ? lg : -__builtin_huge_valf());
+        if (on) reinterpret_cast<float *>(out)[k] = lgl ? lg - mx : -3.4028234663852886e38f;
+    } else {
+        float e = on ? np_expf(lg) : 0.0f;
+        float es = gsum_np<LANES, float>(e, a, A);
+        float p = __fdiv_rn(e, es);
+        float keep = (float)(1.0 - frac);
+        double noised = (double)(keep * p) + frac * (on ? dirichlet[k] : 0.0);
+        const double tiny = 2.2250738585072014e-308;
+        double l = log(noised > tiny ? noised : tiny);
+        double mx = gmax<LANES>(on ? l : -__builtin_huge_val());
+        if (on) reinterpret_cast<double *>(out)[k] = lgl ? l - mx : -1.7976931348623157e308;
+    }
+}
+
+// One rule at one node, for the module-level functions of the drop-in package.
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int depth, int which,
+                                                 const double *uniform, double *out_vec, int32_t *out_action)
+{
+    int a = threadIdx.x % LANES;
+    if (threadIdx.x >= LANES) return;
+    bool on = a < d.L.A;
+    if (which == 3) {  // selection
+        int child;
+        double u = (uniform && on) ? uniform[a] : 0.0;
+        int act = select_at<LANES, GUMBEL>(d, t, node, depth, a, on, u, &child);
+        if (a == 0) *out_action = act;
+        return;
+    }
+    NodeStats s = load_node<GUMBEL>(d, t, node, a, on);
+    double r;
+    if (which == 0) {
+        r = qt_parent_siblings<LANES>(d, s, on);
+    } else {
+        int vsum;
+        if constexpr (GUMBEL) {
+            if (which == 1) {
+                r = qt_completed_mix<LANES>(d, s, a, on, &vsum);
+            } else {
+                vsum = gsumi<LANES>(on ? s.cv : 0);
+                r = mixed_value<LANES>(d, s, a, on, s.r + d.discount * s.v, vsum);
+            }
+        } else {
+            r = 0.0;
+        }
+    }
+    if (on) out_vec[a] = r;
+}
+
+__global__ void k_stats(Dev d, long long *out_node_visits, int32_t *out_noise_calls)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= d.B) return;
+    if (out_node_visits) out_node_visits[t] = d.visit_total[t];
+    if (out_noise_calls) out_noise_calls[t] = (int32_t)d.noise_calls[t];
+}
+
+// ============================================================================ host side
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(MZ_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct mz_ctx {
+    mz_config cfg;
+    Dev d;
+    int lanes;
+    int n_expanded;   // nodes 1..n_expanded exist (simulations done since reset)
+    int selected;     // 1 between mz_select and mz_expand_backup
+    int B;            // batch of the last reset
+    std::vector<void *> allocs;
+    double *node_tmp;   // device scratch for per-node ops [A]
+    int32_t *node_act;  // device scratch
+};
+
+static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+static void considered_visits_host(int m, int S, int32_t *out)
+{
+    if (m <= 1) { for (int i = 0; i < S; i++) out[i] = i; return; }
+    int log2max = (int)std::ceil(std::log2((double)m));
+    std::vector<int32_t> visits(m, 0);
+    int n_considered = m, len = 0;
+    while (len < S) {
+        int n_extra = (int)((double)S / (double)(log2max * n_considered));
+        if (n_extra < 1) n_extra = 1;
+        for (int e = 0; e < n_extra && len < S; e++) {
+            for (int i = 0; i < n_considered && len < S; i++) out[len++] = visits[i];
+            for (int i = 0; i < n_considered; i++) visits[i]++;
+        }
+        n_considered = n_considered / 2 > 2 ? n_considered / 2 : 2;
+    }
+}
+
+extern "C" int mz_considered_visits(int32_t m, int32_t S, int32_t *out_h)
+{
+    if (S < 0 || m > MZ_MAX_ACTIONS || !out_h) return fail(MZ_ERR_ARG, "mz_considered_visits: bad argument");
+    considered_visits_host(m, S, out_h);
+    return MZ_OK;
+}
+
+extern "C" const char *mz_last_error(void) { return g_err.c_str(); }
+extern "C" int mz_version(void) { return 1; }
+
+template <typename T>
+static int dev_alloc(mz_ctx *c, T **p, size_t n)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, n * sizeof(T) ? n * sizeof(T) : 16));
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T *>(q);
+    return MZ_OK;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" mz_ctx *mz_create(const mz_config *cfg)
+{
+    if (!cfg) { fail(MZ_ERR_ARG, "mz_create: null config"); return nullptr; }
+    const int A = cfg->n_actions, S = cfg->n_simulations;
+    if (A < 1 || A > MZ_MAX_ACTIONS) { fail(MZ_ERR_ARG, "mz_create: n_actions must be in 1..64"); return nullptr; }
+    if (S < 1 || S > (1 << 20)) { fail(MZ_ERR_ARG, "mz_create: n_simulations out of range"); return nullptr; }
+    if (cfg->players != 1 && cfg->players != 2) { fail(MZ_ERR_ARG, "mz_create: players must be 1 or 2"); return nullptr; }
+    if (cfg->max_batch < 1 || cfg->hidden_size < 0) { fail(MZ_ERR_ARG, "mz_create: bad max_batch/hidden_size"); return nullptr; }
+    int lanes = cfg->lanes_per_tree;
+    int l0 = next_pow2(A) < 2 ? 2 : next_pow2(A);
+    if (lanes == 0) {
+        // Small batches: spread each tree over more lanes so the launch still covers the chip's CUs.
+        long long want = 64ll * 2048 / cfg->max_batch;
+        int w = 1;
+        while (2 * w <= want && 2 * w <= 64) w *= 2;
+        lanes = w > l0 ? w : l0;
+    }
+    if (lanes < l0 || lanes > 64 || (lanes & (lanes - 1))) {
+        fail(MZ_ERR_ARG, "mz_create: lanes_per_tree must be a power of two in [n_actions, 64]");
+        return nullptr;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) { fail(MZ_ERR_HIP, "mz_create: hipSetDevice failed"); return nullptr; }
+    mz_ctx *c = new mz_ctx();
+    c->cfg = *cfg;
+    c->cfg.c_table_h = nullptr;
+    c->lanes = lanes;
+    c->n_expanded = 0; c->selected = 0; c->B = 0;
+    Dev &d = c->d;
+    memset(&d, 0, sizeof d);
+    Layout &L = d.L;
+    L.A = A; L.S = S; L.N = S + 1; L.H = cfg->hidden_size;
+    L.prior_f32 = cfg->gumbel ? 1 : 0;
+    L.off_cval = 32;
+    L.off_crew = L.off_cval + 8 * A;
+    L.off_prior = L.off_crew + 8 * A;
+    L.off_cvis = L.off_prior + round_up((cfg->gumbel ? 4 : 8) * A, 8);
+    L.off_cidx = L.off_cvis + 4 * A;
+    L.rec = round_up(L.off_cidx + 4 * A, 64);
+    L.tree_stride = (long long)L.N * L.rec;
+    const size_t B = (size_t)cfg->max_batch;
+    int rc = MZ_OK;
+    rc |= dev_alloc(c, &d.nodes, B * (size_t)L.tree_stride);
+    rc |= dev_alloc(c, &d.hidden, B * L.N * (size_t)L.H);
+    rc |= dev_alloc(c, &d.legal, B);
+    rc |= dev_alloc(c, &d.gumbel, B * A);
+    rc |= dev_alloc(c, &d.m_considered, B);
+    rc |= dev_alloc(c, &d.sel_parent, B);
+    rc |= dev_alloc(c, &d.sel_action, B);
+    rc |= dev_alloc(c, &d.sel_ntp, B);
+    rc |= dev_alloc(c, &d.sel_depth, B);
+    rc |= dev_alloc(c, &d.noise_calls, B);
+    rc |= dev_alloc(c, &d.visit_total, B);
+    rc |= dev_alloc(c, &d.path, B * S);
+    rc |= dev_alloc(c, &d.err, (size_t)1);
+    rc |= dev_alloc(c, &c->node_tmp, (size_t)MZ_MAX_ACTIONS);
+    rc |= dev_alloc(c, &c->node_act, (size_t)1);
+    int32_t *cvt = nullptr;
+    double *ct = nullptr;
+    rc |= dev_alloc(c, &cvt, (size_t)(A + 1) * S);
+    rc |= dev_alloc(c, &ct, (size_t)S + 2);
+    if (rc != MZ_OK) { mz_destroy(c); return nullptr; }
+    std::vector<int32_t> tab((size_t)(A + 1) * S);
+    for (int m = 0; m <= A; m++) considered_visits_host(m, S, tab.data() + (size_t)m * S);
+    std::vector<double> ctab(S + 2);
+    for (int n = 0; n < S + 2; n++)
+        ctab[n] = cfg->c_table_h ? cfg->c_table_h[n]
+                                 : cfg->c_init + std::log(((double)n + cfg->c_base + 1.0) / cfg->c_base);
+    if (hipMemcpy(cvt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ct, ctab.data(), ctab.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(d.err, 0, 4) != hipSuccess || hipMemset(d.sel_depth, 0xff, B * 4) != hipSuccess) {
+        fail(MZ_ERR_HIP, "mz_create: table upload failed");
+        mz_destroy(c);
+        return nullptr;
+    }
+    d.cv_table = cvt; d.c_table = ct;
+    d.players = cfg->players; d.noise_mode = cfg->noise_mode;
+    d.discount = cfg->discount; d.c_visit = cfg->c_visit; d.c_scale = cfg->c_scale;
+    d.seed = cfg->seed;
+    return c;
+}
+
+extern "C" void mz_destroy(mz_ctx *c)
+{
+    if (!c) return;
+    for (void *p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+// Dispatch a kernel template over (lanes, gumbel).
+#define MZ_DISPATCH(c, KERNEL, grid_groups, stream, ...)                                          \
+    do {                                                                                          \
+        hipStream_t st_ = (hipStream_t)(stream);                                                  \
+        const bool g_ = (c)->cfg.gumbel != 0;                                                     \
+        auto launch_ = [&](auto lanes_tag) {                                                      \
+            constexpr int LN = decltype(lanes_tag)::value;                                        \
+            unsigned grid_ = (unsigned)(((long long)(grid_groups) * LN + MZ_BLOCK - 1) / MZ_BLOCK); \
+            if (g_) hipLaunchKernelGGL((KERNEL<LN, true>), dim3(grid_), dim3(MZ_BLOCK), 0, st_, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<LN, false>), dim3(grid_), dim3(MZ_BLOCK), 0, st_, __VA_ARGS__);   \
+        };                                                                                        \
+        switch ((c)->lanes) {                                                                     \
+        case 2: launch_(std::integral_constant<int, 2>()); break;                                 \
+        case 4: launch_(std::integral_constant<int, 4>()); break;                                 \
+        case 8: launch_(std::integral_constant<int, 8>()); break;                                 \
+        case 16: launch_(std::integral_constant<int, 16>()); break;                               \
+        case 32: launch_(std::integral_constant<int, 32>()); break;                               \
+        default: launch_(std::integral_constant<int, 64>()); break;                               \
+        }                                                                                         \
+    } while (0)
+
+static int check_ctx(mz_ctx *c, const char *fn)
+{
+    if (!c) return fail(MZ_ERR_ARG, std::string(fn) + ": null context");
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return fail(MZ_ERR_HIP, std::string(fn) + ": hipSetDevice failed");
+    (void)hipGetLastError();  // a stale error left by other users of the runtime is not ours to report
+    return MZ_OK;
+}
+
+static int launch_status(const char *fn)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MZ_ERR_HIP, std::string(fn) + ": launch failed: " + hipGetErrorString(e));
+    return MZ_OK;
+}
+
+extern "C" int mz_root_prepare(mz_ctx *c, int32_t B, const float *logits, const double *dirichlet,
+                               double frac, const uint8_t *legal, void *out_prior, void *stream)
+{
+    int rc = check_ctx(c, "mz_root_prepare");
+    if (rc) return rc;
+    if (B < 1 || !logits || !legal || !out_prior) return fail(MZ_ERR_ARG, "mz_root_prepare: null/empty argument");
+    if (!c->cfg.gumbel && !dirichlet) return fail(MZ_ERR_ARG, "mz_root_prepare: PUCT needs dirichlet noise");
+    MZ_DISPATCH(c, k_root_prepare, B, stream, (int)B, c->cfg.n_actions, logits, dirichlet, frac, legal, out_prior);
+    return launch_status("mz_root_prepare");
+}
+
+extern "C" int mz_tree_reset(mz_ctx *c, int32_t B, const void *root_prior, const double *root_value,
+                             const float *root_hidden, const int32_t *root_to_play, const uint8_t *legal,
+                             const double *gumbel, uint64_t tree_id0, void *stream)
+{
+    int rc = check_ctx(c, "mz_tree_reset");
+    if (rc) return rc;
+    if (B < 1 || B > c->cfg.max_batch) return fail(MZ_ERR_ARG, "mz_tree_reset: B outside 1..max_batch");
+    if (!root_prior || !root_value || !root_to_play || !legal) return fail(MZ_ERR_ARG, "mz_tree_reset: null argument");
+    if (c->cfg.gumbel && !gumbel) return fail(MZ_ERR_ARG, "mz_tree_reset: Gumbel search needs gumbel noise");
+    c->B = B; c->d.B = B; c->d.tree_id0 = tree_id0;
+    c->n_expanded = 0; c->selected = 0;
+    MZ_DISPATCH(c, k_reset, B, stream, c->d, root_prior, root_value, root_hidden, root_to_play, legal, gumbel,
+                (int)c->cfg.max_considered_actions);
+    return launch_status("mz_tree_reset");
+}
+
+static int check_noise(mz_ctx *c, const double *noise, int32_t max_calls, const char *fn)
+{
+    if (!c->cfg.gumbel && c->cfg.noise_mode == MZ_NOISE_BUFFER && (!noise || max_calls < 1))
+        return fail(MZ_ERR_ARG, std::string(fn) + ": noise_mode is MZ_NOISE_BUFFER but no noise buffer given");
+    return MZ_OK;
+}
+
+extern "C" int mz_select(mz_ctx *c, const double *noise, int32_t noise_max_calls, float *out_parent_hidden,
+                         int32_t *out_parent, int32_t *out_action, void *stream)
+{
+    int rc = check_ctx(c, "mz_select");
+    if (rc) return rc;
+    if (c->B < 1) return fail(MZ_ERR_STATE, "mz_select: no tree (call mz_tree_reset first)");
+    if (c->n_expanded >= c->cfg.n_simulations) return fail(MZ_ERR_STATE, "mz_select: all simulations already done");
+    if ((rc = check_noise(c, noise, noise_max_calls, "mz_select"))) return rc;
+    if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
+    MZ_DISPATCH(c, k_select, c->B, stream, c->d, noise, (int)noise_max_calls, out_parent_hidden, out_parent,
+                out_action);
+    c->selected = 1;
+    return launch_status("mz_select");
+}
+
+extern "C" int mz_select_outputs(mz_ctx *c, const int32_t **parent, const int32_t **action,
+                                 const int32_t **ntp, const int32_t **depth)
+{
+    if (!c) return fail(MZ_ERR_ARG, "mz_select_outputs: null context");
+    if (parent) *parent = c->d.sel_parent;
+    if (action) *action = c->d.sel_action;
+    if (ntp) *ntp = c->d.sel_ntp;
+    if (depth) *depth = c->d.sel_depth;
+    return MZ_OK;
+}
+
+extern "C" int mz_expand_backup(mz_ctx *c, const float *logits, const double *value, const double *reward,
+                                const float *next_hidden, void *stream)
+{
+    int rc = check_ctx(c, "mz_expand_backup");
+    if (rc) return rc;
+    if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup: no pending selection (call mz_select first)");
+    if (!logits || !value || !reward) return fail(MZ_ERR_ARG, "mz_expand_backup: null argument");
+    int leaf = c->n_expanded + 1;
+    MZ_DISPATCH(c, k_expand_backup, c->B, stream, c->d, leaf, logits, value, reward, next_hidden);
+    c->n_expanded = leaf;
+    c->selected = 0;
+    return launch_status("mz_expand_backup");
+}
+
+extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, const double *noise,
+                             int32_t noise_max_calls, void *stream)
+{
+    int rc = check_ctx(c, "mz_search_run");
+    if (rc) return rc;
+    if (c->B < 1) return fail(MZ_ERR_STATE, "mz_search_run: no tree (call mz_tree_reset first)");
+    if (c->selected) return fail(MZ_ERR_STATE, "mz_search_run: a selection is pending");
+    if (net_kind != MZ_NET_HASH) return fail(MZ_ERR_ARG, "mz_search_run: unsupported net_kind");
+    if (!net_params_h) return fail(MZ_ERR_ARG, "mz_search_run: null network parameters");
+    if (c->cfg.hidden_size < 2) return fail(MZ_ERR_ARG, "mz_search_run: hash network needs hidden_size >= 2");
+    if ((rc = check_noise(c, noise, noise_max_calls, "mz_search_run"))) return rc;
+    if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
+    const int32_t *p = reinterpret_cast<const int32_t *>(net_params_h);
+    HashNet hn{p[0], p[1], p[2]};
+    int n_sims = c->cfg.n_simulations - c->n_expanded;
+    if (n_sims <= 0) return fail(MZ_ERR_STATE, "mz_search_run: all simulations already done");
+    MZ_DISPATCH(c, k_search_hash, c->B, stream, c->d, hn, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
+    c->n_expanded += n_sims;
+    return launch_status("mz_search_run");
+}
+
+extern "C" int mz_to_act(mz_ctx *c, double temperature, const double *u, int32_t *out_action,
+                         double *out_probs, double *out_root_value, double *out_q, void *stream)
+{
+    int rc = check_ctx(c, "mz_to_act");
+    if (rc) return rc;
+    if (c->B < 1) return fail(MZ_ERR_STATE, "mz_to_act: no tree");
+    if (!out_action || !out_probs || !out_root_value) return fail(MZ_ERR_ARG, "mz_to_act: null output");
+    MZ_DISPATCH(c, k_to_act, c->B, stream, c->d, temperature, u, out_action, out_probs, out_root_value, out_q);
+    return launch_status("mz_to_act");
+}
+
+extern "C" int mz_stats(mz_ctx *c, int64_t *out_node_visits, int32_t *out_noise_calls, void *stream)
+{
+    int rc = check_ctx(c, "mz_stats");
+    if (rc) return rc;
+    if (c->B < 1) return fail(MZ_ERR_STATE, "mz_stats: no tree");
+    hipLaunchKernelGGL(k_stats, dim3((c->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d,
+                       reinterpret_cast<long long *>(out_node_visits), out_noise_calls);
+    return launch_status("mz_stats");
+}
+
+static int device_error(mz_ctx *c, hipStream_t st, const char *fn)
+{
+    int32_t e = 0;
+    HIPCHK(hipMemcpyAsync(&e, c->d.err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (e) {
+        (void)hipMemsetAsync(c->d.err, 0, 4, st);
+        return fail(MZ_ERR_DEVICE, std::string(fn) + ": a kernel reported an inconsistent selection state");
+    }
+    return MZ_OK;
+}
+
+extern "C" int mz_tree_export(mz_ctx *c, int32_t b, mz_tree_host *o, void *stream)
+{
+    int rc = check_ctx(c, "mz_tree_export");
+    if (rc) return rc;
+    if (!o || b < 0 || b >= c->B) return fail(MZ_ERR_ARG, "mz_tree_export: tree index out of range");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = device_error(c, st, "mz_tree_export"))) return rc;
+    const Layout &L = c->d.L;
+    const int A = L.A, N = L.N, H = L.H;
+    std::vector<char> buf((size_t)L.tree_stride);
+    HIPCHK(hipMemcpyAsync(buf.data(), c->d.nodes + (long long)b * L.tree_stride, buf.size(), hipMemcpyDeviceToHost, st));
+    if (o->hidden_states && H > 0)
+        HIPCHK(hipMemcpyAsync(o->hidden_states, c->d.hidden + (long long)b * N * H, (size_t)N * H * 4,
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int n = 0; n < N; n++) {
+        const char *r = buf.data() + (size_t)n * L.rec;
+        bool live = n <= c->n_expanded;
+        NodeHdr h;
+        memcpy(&h, r, sizeof h);
+        o->node_visits[n] = live ? h.visits : 0;
+        o->node_values[n] = live ? h.value : 0.0;
+        o->node_raw_values[n] = live ? h.raw : 0.0;
+        o->parents[n] = live ? h.parent : -1;
+        o->action_from_parent[n] = live ? h.afp : -1;
+        o->to_play[n] = live ? h.to_play : 0;
+        for (int a = 0; a < A; a++) {
+            size_t k = (size_t)n * A + a;
+            if (live) {
+                memcpy(&o->children_values[k], r + L.off_cval + 8 * a, 8);
+                memcpy(&o->children_rewards[k], r + L.off_crew + 8 * a, 8);
+                memcpy(&o->children_visits[k], r + L.off_cvis + 4 * a, 4);
+                memcpy(&o->children_index[k], r + L.off_cidx + 4 * a, 4);
+                if (L.prior_f32) memcpy((float *)o->children_prior_logits + k, r + L.off_prior + 4 * a, 4);
+                else memcpy((double *)o->children_prior_logits + k, r + L.off_prior + 8 * a, 8);
+            } else {
+                o->children_values[k] = 0; o->children_rewards[k] = 0;
+                o->children_visits[k] = 0; o->children_index[k] = -1;
+                if (L.prior_f32) ((float *)o->children_prior_logits)[k] = 0;
+                else ((double *)o->children_prior_logits)[k] = 0;
+            }
+        }
+        if (!live && o->hidden_states && H > 0) memset(o->hidden_states + (size_t)n * H, 0, (size_t)H * 4);
+    }
+    return MZ_OK;
+}
+
+extern "C" int mz_tree_import(mz_ctx *c, int32_t b, const mz_tree_host *in, const double *root_legal_h,
+                              const double *gumbel_h, void *stream)
+{
+    int rc = check_ctx(c, "mz_tree_import");
+    if (rc) return rc;
+    if (!in || !root_legal_h || b < 0 || b >= c->cfg.max_batch) return fail(MZ_ERR_ARG, "mz_tree_import: bad argument");
+    if (c->cfg.gumbel && !gumbel_h) return fail(MZ_ERR_ARG, "mz_tree_import: Gumbel tree needs gumbel noise");
+    hipStream_t st = (hipStream_t)stream;
+    const Layout &L = c->d.L;
+    const int A = L.A, N = L.N, H = L.H;
+    std::vector<char> buf((size_t)L.tree_stride, 0);
+    int live = 0;
+    for (int n = 0; n < N; n++) {
+        char *r = buf.data() + (size_t)n * L.rec;
+        NodeHdr h;
+        h.visits = in->node_visits[n]; h.parent = in->parents[n]; h.afp = in->action_from_parent[n];
+        h.to_play = in->to_play[n]; h.value = in->node_values[n]; h.raw = in->node_raw_values[n];
+        if (h.visits > 0) live = n;
+        memcpy(r, &h, sizeof h);
+        for (int a = 0; a < A; a++) {
+            size_t k = (size_t)n * A + a;
+            memcpy(r + L.off_cval + 8 * a, &in->children_values[k], 8);
+            memcpy(r + L.off_crew + 8 * a, &in->children_rewards[k], 8);
+            memcpy(r + L.off_cvis + 4 * a, &in->children_visits[k], 4);
+            memcpy(r + L.off_cidx + 4 * a, &in->children_index[k], 4);
+            if (L.prior_f32) memcpy(r + L.off_prior + 4 * a, (const float *)in->children_prior_logits + k, 4);
+            else memcpy(r + L.off_prior + 8 * a, (const double *)in->children_prior_logits + k, 8);
+        }
+    }
+    unsigned long long mask = 0;
+    int n_legal = 0;
+    for (int a = 0; a < A; a++) if (root_legal_h[a] != 0) { mask |= 1ull << a; n_legal++; }
+    int32_t m = c->cfg.max_considered_actions < n_legal ? c->cfg.max_considered_actions : n_legal;
+    HIPCHK(hipMemcpyAsync(c->d.nodes + (long long)b * L.tree_stride, buf.data(), buf.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d.legal + b, &mask, 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d.m_considered + b, &m, 4, hipMemcpyHostToDevice, st));
+    if (gumbel_h) HIPCHK(hipMemcpyAsync(c->d.gumbel + (long long)b * A, gumbel_h, (size_t)A * 8, hipMemcpyHostToDevice, st));
+    if (in->hidden_states && H > 0)
+        HIPCHK(hipMemcpyAsync(c->d.hidden + (long long)b * N * H, in->hidden_states, (size_t)N * H * 4,
+                              hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (b >= c->B) { c->B = b + 1; c->d.B = c->B; }
+    if (live > c->n_expanded) c->n_expanded = live;
+    return MZ_OK;
+}
+
+static int node_op(mz_ctx *c, int32_t b, int32_t node, int depth, int which, const double *uniform_h,
+                   double *out_vec_h, int32_t *out_action_h, void *stream, const char *fn)
+{
+    int rc = check_ctx(c, fn);
+    if (rc) return rc;
+    if (b < 0 || b >= c->B || node < 0 || node >= c->d.L.N) return fail(MZ_ERR_ARG, std::string(fn) + ": tree/node out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const int A = c->d.L.A;
+    double *u_d = nullptr;
+    if (uniform_h) {
+        u_d = c->node_tmp;
+        HIPCHK(hipMemcpyAsync(u_d, uniform_h, (size_t)A * 8, hipMemcpyHostToDevice, st));
+    }
+    double *vec_d = c->node_tmp;
+    const bool g = c->cfg.gumbel != 0;
+    auto launch = [&](auto tag) {
+        constexpr int LN = decltype(tag)::value;
+        if (g) hipLaunchKernelGGL((k_node_op<LN, true>), dim3(1), dim3(64), 0, st, c->d, (int)b, (int)node, depth, which, u_d, vec_d, c->node_act);
+        else hipLaunchKernelGGL((k_node_op<LN, false>), dim3(1), dim3(64), 0, st, c->d, (int)b, (int)node, depth, which, u_d, vec_d, c->node_act);
+    };
+    switch (c->lanes) {
+    case 2: launch(std::integral_constant<int, 2>()); break;
+    case 4: launch(std::integral_constant<int, 4>()); break;
+    case 8: launch(std::integral_constant<int, 8>()); break;
+    case 16: launch(std::integral_constant<int, 16>()); break;
+    case 32: launch(std::integral_constant<int, 32>()); break;
+    default: launch(std::integral_constant<int, 64>()); break;
+    }
+    if ((rc = launch_status(fn))) return rc;
+    if (out_vec_h) HIPCHK(hipMemcpyAsync(out_vec_h, vec_d, (size_t)A * 8, hipMemcpyDeviceToHost, st));
+    if (out_action_h) HIPCHK(hipMemcpyAsync(out_action_h, c->node_act, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return MZ_OK;
+}
+
+extern "C" int mz_node_qtransform(mz_ctx *c, int32_t b, int32_t node, int32_t which, double *out_h, void *stream)
+{
+    if (which < 0 || which > 2 || !out_h) return fail(MZ_ERR_ARG, "mz_node_qtransform: bad argument");
+    if (c && which > 0 && !c->cfg.gumbel)
+        return fail(MZ_ERR_ARG, "mz_node_qtransform: completed-Q transforms need a Gumbel context (float32 priors)");
+    return node_op(c, b, node, 1, which, nullptr, out_h, nullptr, stream, "mz_node_qtransform");
+}
+
+extern "C" int mz_node_select(mz_ctx *c, int32_t b, int32_t node, int32_t depth, const double *uniform_h,
+                              int32_t *out_action_h, void *stream)
+{
+    if (!out_action_h) return fail(MZ_ERR_ARG, "mz_node_select: null output");
+    return node_op(c, b, node, depth, 3, uniform_h, nullptr, out_action_h, stream, "mz_node_select");
+}

@@ -1,0 +1,251 @@
+// Per-tree search steps executed by one lane group: descent (selection), expansion, backup,
+// and the final action rule.  Arithmetic, operand order and dtypes follow the reference's
+// NumPy expressions (cited per function) so every tree field comes out bit-identical.
+#pragma once
+#include "device_common.h"
+
+namespace mz {
+
+struct RowView {
+    NodeHdr *hdr;
+    double *cval, *crew;
+    void *prior;
+    int32_t *cvis, *cidx;
+};
+
+__device__ __forceinline__ RowView view(const Dev &d, int t, int n)
+{
+    char *r = node_rec(d, t, n);
+    RowView v;
+    v.hdr = reinterpret_cast<NodeHdr *>(r);
+    v.cval = reinterpret_cast<double *>(r + d.L.off_cval);
+    v.crew = reinterpret_cast<double *>(r + d.L.off_crew);
+    v.prior = r + d.L.off_prior;
+    v.cvis = reinterpret_cast<int32_t *>(r + d.L.off_cvis);
+    v.cidx = reinterpret_cast<int32_t *>(r + d.L.off_cidx);
+    return v;
+}
+
+struct NodeStats {  // what lane `a` holds of the node being scored
+    int nv;           // node_visits[node]
+    double nval, raw; // node_values[node], node_raw_values[node]
+    int cv, ci;       // children_visits[node, a], children_index[node, a]
+    double prior;     // children_prior_logits[node, a] (exact: f32 priors widen losslessly)
+    double r, v;      // children_rewards[node, a], children_values[node, a]
+};
+
+template <bool GUMBEL>
+__device__ __forceinline__ NodeStats load_node(const Dev &d, int t, int node, int a, bool on)
+{
+    RowView w = view(d, t, node);
+    NodeStats s;
+    s.nv = w.hdr->visits;
+    s.nval = w.hdr->value;
+    s.raw = w.hdr->raw;
+    s.cv = 0; s.ci = -1; s.prior = 0; s.r = 0; s.v = 0;
+    if (on) {
+        s.cv = w.cvis[a];
+        s.ci = w.cidx[a];
+        s.prior = GUMBEL ? (double)reinterpret_cast<float *>(w.prior)[a]
+                         : reinterpret_cast<double *>(w.prior)[a];
+        s.r = w.crew[a];
+        s.v = w.cval[a];
+    }
+    return s;
+}
+
+// mcts/qtransforms.py:7-22 (with Tree.qvalues, mcts/tree.py:55-58)
+template <int LANES>
+__device__ __forceinline__ double qt_parent_siblings(const Dev &d, const NodeStats &s, bool on)
+{
+    const double inf = __builtin_huge_val();
+    double q = s.r + d.discount * s.v;
+    double safe = s.cv > 0 ? q : s.nval;
+    double lo = gmin<LANES>(on ? safe : inf), hi = gmax<LANES>(on ? safe : -inf);
+    lo = s.nval < lo ? s.nval : lo;
+    hi = s.nval > hi ? s.nval : hi;
+    double den = hi - lo;
+    den = den > 1e-8 ? den : 1e-8;
+    double cq = s.cv > 0 ? q : lo;
+    return (cq - lo) / den;
+}
+
+// mcts/qtransforms.py:51-77: the per-action vector the reference's compute_mixed_value yields.
+template <int LANES>
+__device__ __forceinline__ double mixed_value(const Dev &d, const NodeStats &s, int a, bool on,
+                                              double q, int vsum)
+{
+    const int A = d.L.A;
+    float e = on ? np_expf((float)s.prior) : 0.0f;
+    float es = gsum_np<LANES, float>(e, a, A);
+    float p = __fdiv_rn(e, es);
+    const float tiny = 1.17549435e-38f;
+    p = p > tiny ? p : tiny;
+    float pm = (on && s.cv > 0) ? p : 0.0f;
+    float prob_sum = gsum_np<LANES, float>(pm, a, A);
+    double pq = (on && s.cv > 0) ? (double)p * q : 0.0;
+    double sum_pq = gsum_np<LANES, double>(pq, a, A);
+    float denf = s.cv > 0 ? prob_sum : 1.0f;
+    double wq = sum_pq / (double)denf;
+    return (s.raw + (double)vsum * wq) / (double)(vsum + 1);
+}
+
+// mcts/qtransforms.py:25-48
+template <int LANES>
+__device__ __forceinline__ double qt_completed_mix(const Dev &d, const NodeStats &s, int a, bool on,
+                                                   int *vsum_out)
+{
+    const double inf = __builtin_huge_val();
+    double q = s.r + d.discount * s.v;
+    int vsum = gsumi<LANES>(on ? s.cv : 0);
+    int vmax = gmaxi<LANES>(on ? s.cv : -2147483647);
+    double mixed = mixed_value<LANES>(d, s, a, on, q, vsum);
+    double comp = s.cv > 0 ? q : mixed;
+    double lo = gmin<LANES>(on ? comp : inf), hi = gmax<LANES>(on ? comp : -inf);
+    double den = hi - lo;
+    den = den > 1e-8 ? den : 1e-8;
+    double scale = (d.c_visit + (double)vmax) * d.c_scale;
+    *vsum_out = vsum;
+    return scale * ((comp - lo) / den);
+}
+
+// mcts/action_selection.py:147-157
+template <int LANES>
+__device__ __forceinline__ double gumbel_score(const NodeStats &s, bool on, double g, double cq, int considered)
+{
+    const float ninf = -__builtin_huge_valf();
+    float lmax = gmaxf<LANES>(on ? (float)s.prior : ninf);
+    float l = (float)s.prior - lmax;
+    double sc = (g + (double)l) + cq;
+    sc = sc > -1e9 ? sc : -1e9;
+    return sc + (s.cv == considered ? 0.0 : -__builtin_huge_val());
+}
+
+// One selection call at `node` (mcts/action_selection.py:11-22 switch; :25-49 PUCT;
+// :73-96 Gumbel root; :99-118 Gumbel interior).  `u` is this lane's tie-break uniform (PUCT).
+template <int LANES, bool GUMBEL>
+__device__ __forceinline__ int select_at(const Dev &d, int t, int node, int depth, int a, bool on,
+                                         double u, int *child_out)
+{
+    const double inf = __builtin_huge_val();
+    NodeStats s = load_node<GUMBEL>(d, t, node, a, on);
+    bool legal = depth != 0 || ((d.legal[t] >> a) & 1ull);
+    double score;
+    if constexpr (!GUMBEL) {
+        double nq = qt_parent_siblings<LANES>(d, s, on);
+        double cc = d.c_table[s.nv];
+        double uu = cc * s.prior + sqrt((double)s.nv / (double)(1 + s.cv));
+        score = (uu + nq) + 1e-7 * u;
+    } else {
+        int vsum;
+        double cq = qt_completed_mix<LANES>(d, s, a, on, &vsum);
+        if (depth == 0) {
+            int considered = d.cv_table[(long long)d.m_considered[t] * d.L.S + vsum];
+            score = gumbel_score<LANES>(s, on, on ? d.gumbel[(long long)t * d.L.A + a] : 0.0, cq, considered);
+        } else {
+            double e = on ? exp(s.prior + cq) : 0.0;
+            double es = gsum_np<LANES, double>(e, a, d.L.A);
+            score = e / es - (double)s.cv / (double)(1 + vsum);
+        }
+    }
+    if (!on || !legal) score = -inf;
+    int best = gargmax<LANES>(score, on ? a : 0x7fffffff);
+    *child_out = gshfl<LANES>(s.ci, best);
+    return best;
+}
+
+// MCTS.simulate, mcts/mcts.py:98-114.  Returns the parent node; action/next_to_play/depth by reference.
+// Records the path for the backup.  noise: MZ_NOISE_BUFFER rows for this tree, or NULL.
+template <int LANES, bool GUMBEL>
+__device__ __forceinline__ int descend(const Dev &d, int t, int a, bool on, const double *noise,
+                                       int noise_max_calls, int *action_out, int *ntp_out, int *depth_out)
+{
+    int node = 0, depth = 0, ntp = 0, action = 0;
+    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
+    const unsigned long long tree = d.tree_id0 + (unsigned long long)t;
+    int32_t *path = d.path + (long long)t * d.L.S;
+    while (true) {
+        double u = 0.0;
+        if constexpr (!GUMBEL) {
+            if (on) {
+                if (d.noise_mode == 0) u = noise_u(d.seed, tree, calls, (unsigned)a);
+                else if (d.noise_mode == 1 && (int)calls < noise_max_calls)
+                    u = noise[(long long)calls * d.L.A + a];
+            }
+            calls++;
+        }
+        int child;
+        action = select_at<LANES, GUMBEL>(d, t, node, depth, a, on, u, &child);
+        if (a == 0 && depth < d.L.S) path[depth] = (node << 6) | action;
+        ntp = d.players == 1 ? ntp : 1 - ntp;
+        depth++;
+        if (child < 0 || depth > d.L.S) break;  // depth bound: a malformed tree cannot spin forever
+        node = child;
+    }
+    if constexpr (!GUMBEL) { if (a == 0) d.noise_calls[t] = calls; }
+    *action_out = action; *ntp_out = ntp; *depth_out = depth;
+    return node;
+}
+
+// MCTS.expand (mcts/mcts.py:116-141) for leaf index `leaf`, then MCTS.backward (:143-164) along the
+// recorded path.  `logit` is this lane's prior logit; value/reward are group-uniform.
+template <int LANES, bool GUMBEL>
+__device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool on, int parent, int action,
+                                              int ntp, int depth, int leaf, float logit, double value,
+                                              double reward)
+{
+    // --- expansion: a fresh record for the leaf, links in the parent
+    RowView lf = view(d, t, leaf);
+    if (a == 0) {
+        NodeHdr h;
+        h.visits = 1; h.parent = parent; h.afp = action; h.to_play = ntp; h.value = value; h.raw = value;
+        *lf.hdr = h;
+        RowView pr = view(d, t, parent);
+        pr.cidx[action] = leaf;
+        pr.crew[action] = reward;
+    }
+    if (on) {
+        lf.cval[a] = 0.0; lf.crew[a] = 0.0; lf.cvis[a] = 0; lf.cidx[a] = -1;
+        if (GUMBEL) reinterpret_cast<float *>(lf.prior)[a] = logit;
+        else reinterpret_cast<double *>(lf.prior)[a] = (double)logit;
+    }
+    // --- backup: lane i of a chunk owns level i above the leaf; loads are independent, only the
+    // discounted return L is a serial recurrence (reward + gamma * L, mcts/mcts.py:162).
+    const int32_t *path = d.path + (long long)t * d.L.S;
+    double L = value, carry = value;
+    for (int base = 0; base < depth; base += LANES) {
+        int i = base + a;
+        bool valid = i < depth;
+        int p = 0, pa = 0, nv = 0, tp = 0, cvs = 0;
+        double V = 0, r = 0;
+        RowView pw;
+        if (valid) {
+            int pk = path[depth - 1 - i];
+            p = pk >> 6; pa = pk & 63;
+            pw = view(d, t, p);
+            nv = pw.hdr->visits; V = pw.hdr->value; tp = pw.hdr->to_play;
+            r = i == 0 ? reward : pw.crew[pa];
+            cvs = pw.cvis[pa];
+        }
+        int cnt = depth - base < LANES ? depth - base : LANES;
+        double myL = 0;
+        for (int j = 0; j < cnt; j++) {
+            double rj = gshfl<LANES>(r, j);
+            if (a == j) myL = L;
+            L = rj + d.discount * L;
+        }
+        double newV = (V * (double)nv + (tp == ntp ? myL : -myL)) / (double)(nv + 1);
+        double below = __shfl_up(newV, 1, LANES);
+        double child_new = a == 0 ? carry : below;
+        carry = gshfl<LANES>(newV, cnt - 1);
+        if (valid) {
+            pw.hdr->visits = nv + 1;
+            pw.hdr->value = newV;
+            pw.cval[pa] = child_new;
+            pw.cvis[pa] = cvs + 1;
+        }
+    }
+    if (a == 0) d.visit_total[t] += depth + 1;
+}
+
+}  // namespace mz

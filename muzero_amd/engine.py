@@ -1,0 +1,303 @@
+"""ctypes binding of libmuzero_amd.so and the batched search engine built on it.
+
+PyTorch is used for device memory and streams only; every search step runs in
+the HIP kernels of muzero_amd/csrc.  There is no CPU fallback: if the shared
+library is missing, importing this module's engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libmuzero_amd.so')
+_lib = None
+
+NOISE_COUNTER, NOISE_BUFFER, NOISE_NONE = 0, 1, 2
+NET_HASH, NET_MLP = 0, 1
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class MzConfig(C.Structure):
+    _fields_ = [('n_actions', C.c_int32), ('n_simulations', C.c_int32), ('players', C.c_int32),
+                ('gumbel', C.c_int32), ('hidden_size', C.c_int32), ('max_batch', C.c_int32),
+                ('discount', C.c_double), ('c_base', C.c_double), ('c_init', C.c_double),
+                ('max_considered_actions', C.c_int32), ('noise_mode', C.c_int32),
+                ('c_visit', C.c_double), ('c_scale', C.c_double), ('seed', C.c_uint64),
+                ('c_table_h', C.c_void_p), ('device', C.c_int32), ('lanes_per_tree', C.c_int32)]
+
+
+class MzTreeHost(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'node_visits', 'node_values', 'node_raw_values', 'parents', 'action_from_parent', 'to_play',
+        'children_index', 'children_prior_logits', 'children_visits', 'children_rewards',
+        'children_values', 'hidden_states')]
+
+
+EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_tree_export',
+           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_tree_import', 'mz_considered_visits',
+           'mz_version']
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise EngineError(f'{_LIB_PATH} is missing: build it with `python -m muzero_amd.build` '
+                              '(hipcc, gfx950). There is no CPU fallback.')
+        L = C.CDLL(_LIB_PATH)
+        L.mz_create.restype = C.c_void_p
+        L.mz_create.argtypes = [C.POINTER(MzConfig)]
+        L.mz_destroy.argtypes = [C.c_void_p]
+        L.mz_destroy.restype = None
+        L.mz_last_error.restype = C.c_char_p
+        vp, i32, f64, u64 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64
+        L.mz_root_prepare.argtypes = [vp, i32, vp, vp, f64, vp, vp, vp]
+        L.mz_tree_reset.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64, vp]
+        L.mz_select.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+        L.mz_select_outputs.argtypes = [vp, vp, vp, vp, vp]
+        L.mz_expand_backup.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.mz_to_act.argtypes = [vp, f64, vp, vp, vp, vp, vp, vp]
+        L.mz_search_run.argtypes = [vp, i32, vp, vp, i32, vp]
+        L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
+        L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
+        L.mz_stats.argtypes = [vp, vp, vp, vp]
+        L.mz_node_qtransform.argtypes = [vp, i32, i32, i32, vp, vp]
+        L.mz_node_select.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+        L.mz_considered_visits.argtypes = [i32, i32, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what=''):
+    if rc != 0:
+        msg = lib().mz_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise EngineError(msg or f'{what} failed with code {rc}')
+
+
+def considered_visits(max_considered_actions: int, simulations: int) -> tuple:
+    """Sequential-halving visit schedule (host entry point of the library)."""
+    out = np.zeros(max(int(simulations), 0), np.int32)
+    _check(lib().mz_considered_visits(int(max_considered_actions), int(simulations),
+                                      out.ctypes.data_as(C.c_void_p)))
+    return tuple(int(x) for x in out)
+
+
+def c_table_numpy(config) -> np.ndarray:
+    """c(n) for n = 0..S+1, evaluated with NumPy exactly as mcts/action_selection.py:43 does on an
+    np.int32 visit count, so the exploration constant matches the reference to the last bit."""
+    n = np.arange(int(config.simulations) + 2, dtype=np.int32)
+    return np.array([config.c_init + np.log((k + config.c_base + 1) / config.c_base) for k in n],
+                    dtype=np.float64)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SearchEngine:
+    """B independent search trees resident on one GPU.
+
+    config: an object with the attributes `MCTS` reads from its config (simulations, n_actions, gamma,
+    players, gumbel, and c_base/c_init or max_considered_actions/c_visit/c_scale).
+    """
+
+    def __init__(self, config, hidden_size: int, max_batch: int, device=None, noise_mode=NOISE_COUNTER,
+                 seed: int = 0, lanes_per_tree: int = 0, c_table=None):
+        if not torch.cuda.is_available():
+            raise EngineError('no GPU visible: the search engine runs on MI355X only')
+        self.config = config
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else
+                                   (device.index if isinstance(device, torch.device) else int(device)))
+        self.A, self.S, self.H = int(config.n_actions), int(config.simulations), int(hidden_size)
+        self.N = self.S + 1
+        self.gumbel = bool(config.gumbel)
+        self.max_batch = int(max_batch)
+        self.noise_mode = noise_mode
+        g = self.gumbel
+        self._c_table = None
+        if not g:
+            self._c_table = np.ascontiguousarray(c_table_numpy(config) if c_table is None else c_table,
+                                                 dtype=np.float64)
+            assert self._c_table.shape == (self.S + 2,)
+        cfg = MzConfig(self.A, self.S, int(config.players), int(g), self.H, self.max_batch,
+                       float(config.gamma), 0.0 if g else float(config.c_base),
+                       0.0 if g else float(config.c_init),
+                       int(config.max_considered_actions) if g else 0, int(noise_mode),
+                       float(config.c_visit) if g else 0.0, float(config.c_scale) if g else 0.0,
+                       int(seed) & 0xFFFFFFFFFFFFFFFF,
+                       None if g else self._c_table.ctypes.data_as(C.c_void_p),
+                       self.device.index, int(lanes_per_tree))
+        self._ctx = lib().mz_create(C.byref(cfg))
+        if not self._ctx:
+            msg = lib().mz_last_error().decode()
+            raise ValueError(msg) if 'mz_create:' in msg and 'hip' not in msg.lower() else EngineError(msg)
+        self.B = 0
+        self.prior_dtype = torch.float32 if g else torch.float64
+        self._parent = self._action = self._phid = None
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            lib().mz_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, x, dtype, shape=None):
+        t = torch.as_tensor(x)
+        if t.dtype != dtype or t.device != self.device:
+            t = t.to(device=self.device, dtype=dtype)
+        t = t.contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f'expected shape {tuple(shape)}, got {tuple(t.shape)}')
+        return t
+
+    # ------------------------------------------------------------------ steps
+    def root_prepare(self, logits, legal, dirichlet=None, exploration_frac=0.0):
+        lg = self._dev(logits, torch.float32)
+        B = lg.shape[0]
+        lg = lg.reshape(B, self.A)
+        le = self._dev(np.asarray(legal) != 0 if not torch.is_tensor(legal) else legal != 0, torch.uint8, (B, self.A))
+        di = None if dirichlet is None else self._dev(dirichlet, torch.float64, (B, self.A))
+        out = torch.empty((B, self.A), dtype=self.prior_dtype, device=self.device)
+        _check(lib().mz_root_prepare(self._ctx, B, _ptr(lg), _ptr(di), float(exploration_frac), _ptr(le),
+                                     _ptr(out), _stream()))
+        return out
+
+    def reset(self, root_prior, root_value, root_hidden, root_to_play, legal, gumbel=None, tree_id0=0):
+        rp = self._dev(root_prior, self.prior_dtype)
+        B = rp.shape[0]
+        rp = rp.reshape(B, self.A)
+        rv = self._dev(root_value, torch.float64).reshape(B)
+        rh = None if root_hidden is None or self.H == 0 else self._dev(root_hidden, torch.float32).reshape(B, self.H)
+        tp = self._dev(root_to_play, torch.int32).reshape(B)
+        le = self._dev(np.asarray(legal) != 0 if not torch.is_tensor(legal) else legal != 0, torch.uint8, (B, self.A))
+        gu = None if gumbel is None else self._dev(gumbel, torch.float64, (B, self.A))
+        _check(lib().mz_tree_reset(self._ctx, B, _ptr(rp), _ptr(rv), _ptr(rh), _ptr(tp), _ptr(le), _ptr(gu),
+                                   C.c_uint64(int(tree_id0)), _stream()))
+        self.B = B
+        self._parent = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._action = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._phid = torch.empty((B, self.H), dtype=torch.float32, device=self.device) if self.H else None
+
+    def select(self, noise=None, want_hidden=True):
+        """One descent per tree.  Returns (parent i32[B], action i32[B], parent_hidden f32[B,H])."""
+        nz, max_calls = None, 0
+        if noise is not None:
+            nz = self._dev(noise, torch.float64)
+            max_calls = nz.numel() // (self.B * self.A)
+            self._noise_keep = nz
+        ph = self._phid if want_hidden else None
+        _check(lib().mz_select(self._ctx, _ptr(nz), max_calls, _ptr(ph), _ptr(self._parent),
+                               _ptr(self._action), _stream()))
+        return self._parent, self._action, ph
+
+    def expand_backup(self, logits, value, reward, next_hidden=None):
+        B = self.B
+        lg = self._dev(logits, torch.float32).reshape(B, self.A)
+        va = self._dev(value, torch.float64).reshape(B)
+        re = self._dev(reward, torch.float64).reshape(B)
+        nh = None if next_hidden is None or self.H == 0 else self._dev(next_hidden, torch.float32).reshape(B, self.H)
+        _check(lib().mz_expand_backup(self._ctx, _ptr(lg), _ptr(va), _ptr(re), _ptr(nh), _stream()))
+
+    def search_hash(self, logit_shift=5, reward_on=1, parent_predicts=1, noise=None):
+        """All simulations in one launch with the built-in synthetic hash network."""
+        params = (C.c_int32 * 3)(int(logit_shift), int(reward_on), int(parent_predicts))
+        nz, max_calls = None, 0
+        if noise is not None:
+            nz = self._dev(noise, torch.float64)
+            max_calls = nz.numel() // (self.B * self.A)
+        _check(lib().mz_search_run(self._ctx, NET_HASH, params, _ptr(nz), max_calls, _stream()))
+
+    def to_act(self, temperature=0.0, u=None):
+        B = self.B
+        uu = None if u is None else self._dev(u, torch.float64).reshape(B)
+        action = torch.empty(B, dtype=torch.int32, device=self.device)
+        probs = torch.empty((B, self.A), dtype=torch.float64, device=self.device)
+        value = torch.empty(B, dtype=torch.float64, device=self.device)
+        q = torch.empty((B, self.A), dtype=torch.float64, device=self.device)
+        _check(lib().mz_to_act(self._ctx, float(temperature), _ptr(uu), _ptr(action), _ptr(probs), _ptr(value),
+                               _ptr(q), _stream()))
+        return action, value, probs, q
+
+    def stats(self):
+        nv = torch.empty(self.B, dtype=torch.int64, device=self.device)
+        nc = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        _check(lib().mz_stats(self._ctx, _ptr(nv), _ptr(nc), _stream()))
+        return nv, nc
+
+    # ------------------------------------------------------------------ host views
+    def _host_arrays(self):
+        N, A = self.N, self.A
+        pd = np.float32 if self.gumbel else np.float64
+        return dict(node_visits=np.zeros(N, np.int32), node_values=np.zeros(N), node_raw_values=np.zeros(N),
+                    parents=np.zeros(N, np.int32), action_from_parent=np.zeros(N, np.int32),
+                    to_play=np.zeros(N, np.int32), children_index=np.zeros((N, A), np.int32),
+                    children_prior_logits=np.zeros((N, A), pd), children_visits=np.zeros((N, A), np.int32),
+                    children_rewards=np.zeros((N, A)), children_values=np.zeros((N, A)),
+                    hidden_states=np.zeros((N, max(self.H, 1)), np.float32))
+
+    @staticmethod
+    def _host_struct(arrs, with_hidden=True):
+        th = MzTreeHost()
+        for k, v in arrs.items():
+            setattr(th, k, v.ctypes.data_as(C.c_void_p))
+        if not with_hidden:
+            th.hidden_states = None
+        return th
+
+    def export_tree(self, b: int) -> dict:
+        """Tree `b` as host arrays named like the fields of the reference's Tree."""
+        arrs = self._host_arrays()
+        th = self._host_struct(arrs, self.H > 0)
+        _check(lib().mz_tree_export(self._ctx, int(b), C.byref(th), _stream()))
+        return arrs
+
+    def import_tree(self, b: int, arrays: dict, root_legal, gumbel_noise=None):
+        arrs = self._host_arrays()
+        for k in arrs:
+            if k == 'hidden_states':
+                if self.H > 0 and arrays.get(k) is not None:
+                    arrs[k][...] = np.asarray(arrays[k], np.float32).reshape(self.N, self.H)
+                continue
+            arrs[k][...] = np.asarray(arrays[k]).reshape(arrs[k].shape)
+        th = self._host_struct(arrs, self.H > 0 and arrays.get('hidden_states') is not None)
+        rl = np.ascontiguousarray(root_legal, np.float64)
+        gn = None if gumbel_noise is None else np.ascontiguousarray(gumbel_noise, np.float64)
+        _check(lib().mz_tree_import(self._ctx, int(b), C.byref(th), rl.ctypes.data_as(C.c_void_p),
+                                    None if gn is None else gn.ctypes.data_as(C.c_void_p), _stream()))
+        self.B = max(self.B, b + 1)
+
+    def node_qtransform(self, b, node, which):
+        out = np.zeros(self.A)
+        _check(lib().mz_node_qtransform(self._ctx, int(b), int(node), int(which), out.ctypes.data_as(C.c_void_p),
+                                        _stream()))
+        return out
+
+    def node_select(self, b, node, depth, uniform=None):
+        act = C.c_int32(-1)
+        u = None if uniform is None else np.ascontiguousarray(uniform, np.float64)
+        _check(lib().mz_node_select(self._ctx, int(b), int(node), int(depth),
+                                    None if u is None else u.ctypes.data_as(C.c_void_p), C.byref(act), _stream()))
+        return int(act.value)
