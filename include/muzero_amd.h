@@ -85,9 +85,11 @@ const char *mz_last_error(void);
 
 /* Replaces add_exploration_noise (mcts/mcts.py:22-31) + mask_illegal_action_logits
  * (utils/game_utils.py:71-78) for B roots.  logits f32[B][A]; dirichlet f64[B][A] (PUCT) or NULL
- * (Gumbel); legal u8[B][A]; out_prior f64[B][A] (PUCT) / f32[B][A] (Gumbel). */
+ * (Gumbel); legal u8[B][A]; out_prior f64[B][A] (PUCT) / f32[B][A] (Gumbel).
+ * shift_and_mask 0 stops after add_exploration_noise (PUCT; `legal` may then be NULL). */
 int mz_root_prepare(mz_ctx *ctx, int32_t B, const float *logits, const double *dirichlet,
-                    double exploration_frac, const uint8_t *legal, void *out_prior, void *stream);
+                    double exploration_frac, const uint8_t *legal, int32_t shift_and_mask,
+                    void *out_prior, void *stream);
 
 /* Replaces initialize_tree's root update (mcts/mcts.py:93-96, update_tree_node :37-57).
  * root_prior: prepared prior logits, f64[B][A] (PUCT) or f32[B][A] (Gumbel); root_value f64[B];
@@ -147,6 +149,8 @@ int mz_node_qtransform(mz_ctx *ctx, int32_t b, int32_t node, int32_t which, doub
  * uniform_h f64[A] or NULL (PUCT tie-break draw).  Returns the action in *out_action_h. */
 int mz_node_select(mz_ctx *ctx, int32_t b, int32_t node, int32_t depth, const double *uniform_h,
                    int32_t *out_action_h, void *stream);
+/* MCTS.backward (mcts/mcts.py:143-164) alone, from node `leaf` of tree b with the leaf's to_play. */
+int mz_node_backward(mz_ctx *ctx, int32_t b, int32_t leaf, int32_t to_play, void *stream);
 /* Uploads host arrays as tree b (inverse of mz_tree_export); root_legal_h f64[A], gumbel_h f64[A] or NULL. */
 int mz_tree_import(mz_ctx *ctx, int32_t b, const mz_tree_host *in_h, const double *root_legal_h,
                    const double *gumbel_h, void *stream);

@@ -204,14 +204,15 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, 
 template <int LANES, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const float *logits,
                                                             const double *dirichlet, double frac,
-                                                            const uint8_t *legal, void *out)
+                                                            const uint8_t *legal, int shift_and_mask,
+                                                            void *out)
 {
     int gid = (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / LANES), a = threadIdx.x % LANES;
     if (gid >= B) return;
     bool on = a < A;
     long long k = (long long)gid * A + a;
     float lg = on ? logits[k] : 0.0f;
-    bool lgl = on && legal[k] != 0;
+    bool lgl = on && (legal ? legal[k] != 0 : true);
     if constexpr (GUMBEL) {
         float mx = gmaxf<LANES>(on ? lg : -__builtin_huge_valf());
         if (on) reinterpret_cast<float *>(out)[k] = lgl ? lg - mx : -3.4028234663852886e38f;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const f
         const double tiny = 2.2250738585072014e-308;
         double l = log(noised > tiny ? noised : tiny);
         double mx = gmax<LANES>(on ? l : -__builtin_huge_val());
+        if (!shift_and_mask) { if (on) reinterpret_cast<double *>(out)[k] = l; return; }
         if (on) reinterpret_cast<double *>(out)[k] = lgl ? l - mx : -1.7976931348623157e308;
     }
 }
@@ -261,6 +263,28 @@ __global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int dept
         }
     }
     if (on) out_vec[a] = r;
+}
+
+// MCTS.backward (mcts/mcts.py:143-164) from an arbitrary node, walking the parent links; one lane.
+__global__ void k_node_backward(Dev d, int t, int leaf, int to_play)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double leaf_value = view(d, t, leaf).hdr->value;
+    for (int guard = 0; leaf != 0 && guard <= d.L.S; guard++) {
+        RowView lf = view(d, t, leaf);
+        int p = lf.hdr->parent, a = lf.hdr->afp;
+        if (p < 0 || p >= d.L.N || a < 0 || a >= d.L.A) { atomicExch(d.err, 1); return; }
+        RowView pw = view(d, t, p);
+        double reward = pw.crew[a];
+        int pv = pw.hdr->visits;
+        double sv = pw.hdr->to_play == to_play ? leaf_value : -leaf_value;
+        pw.hdr->value = (pw.hdr->value * (double)pv + sv) / (double)(pv + 1);
+        pw.hdr->visits = pv + 1;
+        pw.cval[a] = lf.hdr->value;
+        pw.cvis[a] += 1;
+        leaf_value = reward + d.discount * leaf_value;
+        leaf = p;
+    }
 }
 
 __global__ void k_stats(Dev d, long long *out_node_visits, int32_t *out_noise_calls)
@@ -460,13 +484,16 @@ static int launch_status(const char *fn)
 }
 
 extern "C" int mz_root_prepare(mz_ctx *c, int32_t B, const float *logits, const double *dirichlet,
-                               double frac, const uint8_t *legal, void *out_prior, void *stream)
+                               double frac, const uint8_t *legal, int32_t shift_and_mask, void *out_prior,
+                               void *stream)
 {
     int rc = check_ctx(c, "mz_root_prepare");
     if (rc) return rc;
-    if (B < 1 || !logits || !legal || !out_prior) return fail(MZ_ERR_ARG, "mz_root_prepare: null/empty argument");
+    if (B < 1 || !logits || !out_prior) return fail(MZ_ERR_ARG, "mz_root_prepare: null/empty argument");
+    if (!legal && (shift_and_mask || c->cfg.gumbel)) return fail(MZ_ERR_ARG, "mz_root_prepare: legal mask required");
     if (!c->cfg.gumbel && !dirichlet) return fail(MZ_ERR_ARG, "mz_root_prepare: PUCT needs dirichlet noise");
-    MZ_DISPATCH(c, k_root_prepare, B, stream, (int)B, c->cfg.n_actions, logits, dirichlet, frac, legal, out_prior);
+    MZ_DISPATCH(c, k_root_prepare, B, stream, (int)B, c->cfg.n_actions, logits, dirichlet, frac, legal,
+                (int)shift_and_mask, out_prior);
     return launch_status("mz_root_prepare");
 }
 
@@ -728,4 +755,15 @@ extern "C" int mz_node_select(mz_ctx *c, int32_t b, int32_t node, int32_t depth,
 {
     if (!out_action_h) return fail(MZ_ERR_ARG, "mz_node_select: null output");
     return node_op(c, b, node, depth, 3, uniform_h, nullptr, out_action_h, stream, "mz_node_select");
+}
+
+extern "C" int mz_node_backward(mz_ctx *c, int32_t b, int32_t leaf, int32_t to_play, void *stream)
+{
+    int rc = check_ctx(c, "mz_node_backward");
+    if (rc) return rc;
+    if (b < 0 || b >= c->B || leaf < 0 || leaf >= c->d.L.N) return fail(MZ_ERR_ARG, "mz_node_backward: tree/node out of range");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_node_backward, dim3(1), dim3(64), 0, st, c->d, (int)b, (int)leaf, (int)to_play);
+    if ((rc = launch_status("mz_node_backward"))) return rc;
+    return device_error(c, st, "mz_node_backward");
 }

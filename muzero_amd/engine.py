@@ -42,7 +42,7 @@ class MzTreeHost(C.Structure):
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
            'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_tree_export',
-           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_tree_import', 'mz_considered_visits',
+           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits',
            'mz_version']
 
 
@@ -60,7 +60,8 @@ def lib():
         L.mz_destroy.restype = None
         L.mz_last_error.restype = C.c_char_p
         vp, i32, f64, u64 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64
-        L.mz_root_prepare.argtypes = [vp, i32, vp, vp, f64, vp, vp, vp]
+        L.mz_root_prepare.argtypes = [vp, i32, vp, vp, f64, vp, i32, vp, vp]
+        L.mz_node_backward.argtypes = [vp, i32, i32, i32, vp]
         L.mz_tree_reset.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64, vp]
         L.mz_select.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.mz_select_outputs.argtypes = [vp, vp, vp, vp, vp]
@@ -174,15 +175,16 @@ class SearchEngine:
         return t
 
     # ------------------------------------------------------------------ steps
-    def root_prepare(self, logits, legal, dirichlet=None, exploration_frac=0.0):
+    def root_prepare(self, logits, legal, dirichlet=None, exploration_frac=0.0, shift_and_mask=True):
         lg = self._dev(logits, torch.float32)
         B = lg.shape[0]
         lg = lg.reshape(B, self.A)
-        le = self._dev(np.asarray(legal) != 0 if not torch.is_tensor(legal) else legal != 0, torch.uint8, (B, self.A))
+        le = None if legal is None else self._dev(
+            np.asarray(legal) != 0 if not torch.is_tensor(legal) else legal != 0, torch.uint8, (B, self.A))
         di = None if dirichlet is None else self._dev(dirichlet, torch.float64, (B, self.A))
         out = torch.empty((B, self.A), dtype=self.prior_dtype, device=self.device)
         _check(lib().mz_root_prepare(self._ctx, B, _ptr(lg), _ptr(di), float(exploration_frac), _ptr(le),
-                                     _ptr(out), _stream()))
+                                     int(bool(shift_and_mask)), _ptr(out), _stream()))
         return out
 
     def reset(self, root_prior, root_value, root_hidden, root_to_play, legal, gumbel=None, tree_id0=0):
@@ -294,6 +296,9 @@ class SearchEngine:
         _check(lib().mz_node_qtransform(self._ctx, int(b), int(node), int(which), out.ctypes.data_as(C.c_void_p),
                                         _stream()))
         return out
+
+    def node_backward(self, b, leaf, to_play):
+        _check(lib().mz_node_backward(self._ctx, int(b), int(leaf), int(to_play), _stream()))
 
     def node_select(self, b, node, depth, uniform=None):
         act = C.c_int32(-1)

@@ -1,0 +1,246 @@
+"""`MCTS`: the reference's search entry point (mcts/mcts.py:17-252) on the MI355X engine.
+
+`MCTS(config).search(network, observation, legal_actions, action_encoder, to_play, temperature)`
+keeps its signature and return value `(action, root_value, action_probs)`; `search_batch` is the
+batched form the engine is built for.  All tree work (selection, expansion, backup, the final
+action rule, root-prior preparation) runs in the HIP kernels of libmuzero_amd.so.
+
+Random numbers are drawn on the host from the global `np.random` stream in the reference's
+order, so a caller that seeds NumPy sees the same draws consumed:
+  Gumbel: one `np.random.gumbel(size=A)` per search (mcts/mcts.py:211);
+  PUCT:   one `np.random.dirichlet` (mcts/mcts.py:27), one `np.random.uniform(size=A)` per
+          selection call (mcts/action_selection.py:46), one uniform for `np.random.choice`
+          (mcts/action_selection.py:69).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+
+try:
+    from muzero_amd import engine as _engine
+except ImportError:  # imported as the top-level package `mcts`
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from muzero_amd import engine as _engine
+
+from .tree import Tree
+
+
+def _to_numpy(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+class MCTS:
+
+    def __init__(self, config) -> None:
+        self.config = config
+        self._engines = {}
+        self.last_engine: Optional[_engine.SearchEngine] = None
+        self._last_meta = None
+
+    # ------------------------------------------------------------------ engine cache
+    def _engine_for(self, hidden_size: int, batch: int, noise_mode: int, seed: int = 0):
+        key = (hidden_size, noise_mode)
+        eng = self._engines.get(key)
+        if eng is None or eng.max_batch < batch:
+            if eng is not None:
+                eng.close()
+            eng = _engine.SearchEngine(self.config, hidden_size, max(batch, 1), noise_mode=noise_mode, seed=seed)
+            self._engines[key] = eng
+        return eng
+
+    # ------------------------------------------------------------------ search
+    def search(self, network, observation: np.ndarray, legal_actions: np.ndarray,
+               action_encoder: Callable, to_play: int, temperature: float = 0
+               ) -> Tuple[int, float, np.ndarray]:
+        """One position; consumes the global NumPy stream exactly like the reference."""
+        actions, values, probs = self._search(network, np.asarray(observation)[None],
+                                              np.asarray(legal_actions)[None], [to_play], temperature,
+                                              action_encoder, stream_noise=True)
+        return actions[0], values[0], probs[0]
+
+    def search_batch(self, network, observations, legal_actions, to_play, temperature: float = 0,
+                     action_encoder: Optional[Callable] = None, seed: int = 0, tree_id0: int = 0):
+        """B independent positions at once.  Root noise (Gumbel / Dirichlet / the final sampling
+        uniform) is drawn from `np.random` per tree in batch order; the per-selection tie-break
+        uniforms are counter-based (`muzero_amd/noise.py`) keyed by (seed, tree_id0 + b)."""
+        return self._search(network, observations, legal_actions, to_play, temperature, action_encoder,
+                            stream_noise=False, seed=seed, tree_id0=tree_id0)
+
+    def _search(self, network, observations, legal_actions, to_play, temperature, action_encoder,
+                stream_noise, seed=0, tree_id0=0):
+        cfg = self.config
+        A, S = int(cfg.n_actions), int(cfg.simulations)
+        obs = torch.as_tensor(np.asarray(observations), dtype=torch.float32)
+        B = obs.shape[0]
+        legal = np.asarray(legal_actions, dtype=np.float64).reshape(B, A)
+        with torch.no_grad():
+            logits, hidden, value = network.initial_inference(obs)
+        hidden_shape = tuple(hidden.shape[1:])
+        H = int(np.prod(hidden_shape))
+        gumbel = bool(cfg.gumbel)
+        noise_mode = _engine.NOISE_BUFFER if (stream_noise and not gumbel) else _engine.NOISE_COUNTER
+        eng = self._engine_for(H, B, noise_mode, seed)
+        dev = eng.device
+        g = dirichlet = None
+        if gumbel:
+            g = np.stack([np.random.gumbel(size=A) for _ in range(B)])
+            prior = eng.root_prepare(logits.reshape(B, A), legal)
+        else:
+            dirichlet = np.stack([np.random.dirichlet([cfg.dirichlet_alpha] * A) for _ in range(B)])
+            prior = eng.root_prepare(logits.reshape(B, A), legal, dirichlet, cfg.exploration_frac)
+        eng.reset(prior, value.reshape(B), hidden.reshape(B, H), np.asarray(to_play, dtype=np.int32).reshape(B),
+                  legal, g, tree_id0=tree_id0)
+        noise = rng_state = None
+        if noise_mode == _engine.NOISE_BUFFER:
+            # Pre-draw the longest possible run of per-selection rows (a chain tree makes
+            # S(S+1)/2 calls), then rewind the stream to exactly the rows that were consumed.
+            rng_state = np.random.get_state()
+            noise = torch.as_tensor(np.random.uniform(size=(B, S * (S + 1) // 2, A)), device=dev)
+        net_dev = getattr(network, 'device', None)
+        for _ in range(S):
+            parent, action, phid = eng.select(noise)
+            with torch.no_grad():
+                if hasattr(network, 'recurrent_flat'):
+                    h_in = phid if net_dev == dev else phid.to(network.device)
+                    lg, nh, val, rew = network.recurrent_flat(h_in, network.encode_actions(action.to(h_in.device)))
+                else:
+                    acts = action.cpu().numpy()
+                    enc = torch.as_tensor(np.stack([np.asarray(action_encoder(int(a))) for a in acts]),
+                                          dtype=torch.float32)
+                    lg, nh, val, rew = network.recurrent_inference(phid.cpu().reshape(B, *hidden_shape), enc)
+            eng.expand_backup(lg.reshape(B, A), val.reshape(B), rew.reshape(B), nh.reshape(B, H))
+        u = None
+        if not gumbel:
+            if rng_state is not None:
+                _, calls = eng.stats()
+                np.random.set_state(rng_state)
+                for n in calls.cpu().numpy():  # advance past the rows the search used
+                    np.random.uniform(size=(int(n), A))
+            u = np.array([np.random.random_sample() for _ in range(B)])
+        action, root_value, probs, _ = eng.to_act(float(temperature), u)
+        self.last_engine = eng
+        self._last_meta = (legal, g)
+        a = action.cpu().numpy().astype(np.int64)
+        v = root_value.cpu().numpy()
+        p = probs.cpu().numpy()
+        return a, v, p
+
+    def last_tree(self, b: int = 0) -> Tree:
+        """The tree of batch slot `b` from the most recent search, as host arrays."""
+        eng = self.last_engine
+        arrs = eng.export_tree(b)
+        legal, g = self._last_meta
+        hid = arrs.pop('hidden_states')
+        return Tree(hidden_states=hid, root_legal_actions=legal[b], discount=self.config.gamma,
+                    gumbel_noise=None if g is None else g[b], **arrs)
+
+    # ------------------------------------------------------------------ single-tree methods
+    # The reference exposes the steps of one search as methods that take and return a `Tree` of
+    # host arrays mutated in place.  They are kept for callers that drive a search step by step;
+    # arithmetic steps run through a one-tree engine context, array bookkeeping is plain assignment.
+
+    def add_exploration_noise(self, prior_logits: np.ndarray) -> np.ndarray:
+        """log((1 - f) * softmax(logits) + f * Dirichlet(alpha)) (mcts/mcts.py:22-31)."""
+        A = len(prior_logits)
+        noises = np.random.dirichlet([self.config.dirichlet_alpha] * A)
+        eng = self._engine_for(0, 1, _engine.NOISE_NONE)
+        out = eng.root_prepare(np.asarray(prior_logits, np.float32)[None], None, noises[None],
+                               self.config.exploration_frac, shift_and_mask=False)
+        return out[0].cpu().numpy()
+
+    def update(self, attr, v, index):
+        attr[index] = v
+        return attr
+
+    def update_tree_node(self, tree: Tree, node_index: int, prior_logits, hidden_state, value,
+                         to_play: int) -> Tree:
+        """Writes one node's evaluation into the arrays (mcts/mcts.py:37-57)."""
+        tree.children_prior_logits[node_index] = np.asarray(prior_logits).reshape(-1)
+        tree.node_visits[node_index] += 1
+        v = np.asarray(value).reshape(-1)[0]
+        tree.node_values[node_index] = v
+        tree.node_raw_values[node_index] = v
+        tree.hidden_states[node_index] = hidden_state
+        tree.to_play[node_index] = to_play
+        return tree
+
+    def initialize_tree(self, prior_logits, hidden_state, value, to_play: int, root_legal_actions,
+                        gumbel_noise) -> Tree:
+        """Fresh arrays for simulations+1 nodes with the root filled in (mcts/mcts.py:59-96)."""
+        N, A = self.config.simulations + 1, self.config.n_actions
+        value = np.asarray(value)
+        prior_logits = np.asarray(prior_logits)
+        hidden_state = np.asarray(hidden_state)
+        tree = Tree(
+            node_visits=np.zeros(N, np.int32), node_values=np.zeros(N, value.dtype),
+            node_raw_values=np.zeros(N, value.dtype), parents=np.full(N, Tree.NO_PARENT, np.int32),
+            action_from_parent=np.full(N, Tree.NO_PARENT, np.int32),
+            children_index=np.full((N, A), Tree.UNVISITED, np.int32),
+            children_prior_logits=np.zeros((N, A), prior_logits.dtype),
+            children_visits=np.zeros((N, A), np.int32), children_rewards=np.zeros((N, A), value.dtype),
+            children_values=np.zeros((N, A), value.dtype),
+            hidden_states=np.zeros((N,) + hidden_state.shape, hidden_state.dtype),
+            to_play=np.full(N, Tree.P1, np.int32), root_legal_actions=root_legal_actions,
+            discount=self.config.gamma, gumbel_noise=gumbel_noise)
+        return self.update_tree_node(tree, Tree.ROOT_INDEX, prior_logits, hidden_state, value, to_play)
+
+    def simulate(self, tree: Tree, action_selection_func: Callable) -> Tuple[int, int, int]:
+        """Descends with `action_selection_func(tree, node, depth)` until an unexpanded edge
+        (mcts/mcts.py:98-114); `next_to_play` starts from player 0 whatever the root's to_play is."""
+        nxt, to_play, depth = Tree.ROOT_INDEX, Tree.P1, 0
+        while nxt != Tree.UNVISITED:
+            node = nxt
+            action = action_selection_func(tree, node, depth)
+            nxt = tree.children_index[node, action]
+            if self.config.players not in (1, 2):
+                raise AssertionError('The project supports 1P and 2P games only.')
+            to_play = to_play if self.config.players == 1 else 1 - to_play
+            depth += 1
+        return node, action, to_play
+
+    def expand(self, tree: Tree, node_index: int, action: int, next_node_index: int, prior_logits,
+               hidden_state, reward, value, next_to_play: int) -> Tree:
+        """Creates the child reached by `action` (mcts/mcts.py:116-141)."""
+        self.update_tree_node(tree, next_node_index, prior_logits, hidden_state, value, next_to_play)
+        tree.parents[next_node_index] = node_index
+        tree.action_from_parent[next_node_index] = action
+        tree.children_index[node_index, action] = next_node_index
+        tree.children_rewards[node_index, action] = np.asarray(reward).reshape(-1)[0]
+        return tree
+
+    def backward(self, tree: Tree, leaf_index: int, to_play: int) -> Tree:
+        """Backs the leaf value up to the root on the device and writes the result into the same
+        host arrays (mcts/mcts.py:143-164)."""
+        from . import _node_engine
+        gumbel = tree.children_prior_logits.dtype == np.float32
+        eng = _node_engine.load(tree, gumbel)
+        eng.node_backward(0, leaf_index, to_play)
+        out = eng.export_tree(0)
+        for k in ('node_visits', 'node_values', 'children_values', 'children_visits'):
+            getattr(tree, k)[...] = out[k].reshape(getattr(tree, k).shape)
+        return tree
+
+    def visualize_tree(self, tree: Tree, output_file: str = None) -> None:
+        """Draws the tree with graphviz (mcts/mcts.py:254-284); needs the optional `pygraphviz`."""
+        import pygraphviz  # imported here: nothing else depends on it
+
+        def node_label(i, reward=0.0):
+            return (f'{i}\nReward: {reward:.2f}\nValue: {tree.node_values[i]:.2f}\n'
+                    f'Visits: {tree.node_visits[i]}\nTo play: {tree.to_play[i]}')
+        graph = pygraphviz.AGraph(directed=True)
+        graph.add_node(0, label=node_label(0), color='green')
+        for n in range(tree.n_simulations):
+            e = np.exp(tree.children_prior_logits[n].astype(np.float64))
+            probs = e / e.sum()
+            q = tree.qvalues(n)
+            for a in range(tree.n_actions):
+                c = tree.children_index[n, a]
+                if c >= 0:
+                    graph.add_node(c, label=node_label(c, tree.children_rewards[n, a]), color='red')
+                    graph.add_edge(n, c, label=f'{a}\nQ: {q[a]:.2f}\np: {probs[a]:.2f}')
+        graph.draw(output_file if output_file is not None else '/tmp/search_tree.png', prog='dot')

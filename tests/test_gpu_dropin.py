@@ -1,0 +1,171 @@
+"""GPU: the drop-in `mcts` package (reference call signatures) against the reference's outputs."""
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, hash_cases, assert_tree_equal, TREE_FIELDS, make_config
+from muzero_amd import hashnet, noise as mznoise
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def mcts_pkg():
+    """Import the package the way a user of the reference would: `from mcts.mcts import MCTS`."""
+    sys.path.insert(0, os.path.join(REPO, 'muzero_amd'))
+    import mcts.mcts as m
+    import mcts.action_selection as asel
+    import mcts.qtransforms as qt
+    import mcts.tree as tr
+    yield m, asel, qt, tr
+    sys.path.remove(os.path.join(REPO, 'muzero_amd'))
+
+
+def test_search_consumes_numpy_stream_like_reference(mcts_pkg):
+    """Seed NumPy, call MCTS.search as self_play.py:92-99 does: same action, root value, policy,
+    same tree, and the global stream is left exactly where the reference leaves it."""
+    m = mcts_pkg[0]
+    for case in hash_cases('search_stream_puct.npz', prefix='s'):
+        hp = hashnet.HashNetParams(case.A, case.H, case.logit_shift, case.reward_on, case.parent_predicts)
+        net = hashnet.HashNetwork(hp)
+        np.random.seed(case.seed)
+        search = m.MCTS(case.cfg)
+        action, root_value, probs = search.search(net, hashnet.observation_of(case.root_code), case['legal'],
+                                                  lambda a: np.eye(case.A)[a], case.to_play,
+                                                  float(case['temperature']))
+        assert np.random.random_sample() == float(case['next_random_sample'])
+        assert int(action) == int(case['action'])
+        assert float(root_value) == float(case['root_value'])
+        np.testing.assert_allclose(probs, case['probs'], rtol=1e-12, atol=1e-300)
+        tree = search.last_tree(0)
+        assert_tree_equal(tree, case, fields=[f for f in TREE_FIELDS if f != 'children_prior_logits'])
+        # prior rows: leaves are the network's logits (exact); the root row went through log() on
+        # the device (<= 1 ulp from NumPy's)
+        got, ref = tree.children_prior_logits, case['children_prior_logits']
+        assert np.array_equal(got[1:], ref[1:])
+        legal = case['legal'] != 0
+        np.testing.assert_allclose(got[0][legal], ref[0][legal], rtol=0, atol=1e-15)
+        assert np.array_equal(got[0][~legal], ref[0][~legal])
+
+
+def test_gumbel_search_drop_in(mcts_pkg):
+    m = mcts_pkg[0]
+    for case in hash_cases('search_hash_gumbel.npz')[::4]:
+        hp = hashnet.HashNetParams(case.A, case.H, case.logit_shift, case.reward_on, case.parent_predicts)
+        net = hashnet.HashNetwork(hp)
+        np.random.seed(case.seed)  # the fixture drew its Gumbel noise from this seed
+        search = m.MCTS(case.cfg)
+        action, root_value, probs = search.search(net, hashnet.observation_of(case.root_code), case['legal'],
+                                                  lambda a: np.eye(case.A)[a], case.to_play)
+        assert int(action) == int(case['action'])
+        assert float(root_value) == float(case['root_value'])
+        np.testing.assert_allclose(probs, case['probs'], rtol=1e-12, atol=1e-300)
+        assert_tree_equal(search.last_tree(0), case)
+
+
+def _step_by_step(m, asel, qt, case):
+    """The reference's own search loop (mcts/mcts.py:181-252) spelled with the drop-in's functions."""
+    cfg = case.cfg
+    hp = hashnet.HashNetParams(case.A, case.H, case.logit_shift, case.reward_on, case.parent_predicts)
+    net = hashnet.HashNetwork(hp)
+    search = m.MCTS(cfg)
+    logits, hidden, value = net.initial_inference(torch.as_tensor(hashnet.observation_of(case.root_code)[None]))
+    logits, hidden, value = logits.numpy().squeeze(), hidden.numpy(), value.numpy().squeeze()
+    if cfg.gumbel:
+        qtf = partial(qt.qtransform_completed_by_mix_value, c_visit=cfg.c_visit, c_scale=cfg.c_scale)
+        root_fn = partial(asel.gumbel_muzero_root_action_selection, discount=cfg.gamma, simulations=cfg.simulations,
+                          max_considered_actions=cfg.max_considered_actions, gumbel_scale=cfg.gumbel_scale,
+                          qtransform=qtf)
+        inner_fn = partial(asel.gumbel_muzero_interior_action_selection, discount=cfg.gamma, qtransform=qtf)
+        prior = case['children_prior_logits'][0]
+        gnoise = case['gumbel_noise']
+    else:
+        root_fn = partial(asel.muzero_action_selection, discount=cfg.gamma, c_base=cfg.c_base, c_init=cfg.c_init,
+                          qtransform=qt.qtransform_by_parent_and_siblings)
+        inner_fn = root_fn
+        prior = case['children_prior_logits'][0]
+        gnoise = None
+    fn = asel.switching_action_selection_wrapper(root_fn, inner_fn)
+    tree = search.initialize_tree(prior, hidden, value, case.to_play, case['legal'], gnoise)
+    for sim in range(cfg.simulations):
+        node, action, ntp = search.simulate(tree, fn)
+        lg, nh, val, rew = net.recurrent_inference(torch.as_tensor(tree.hidden_states[node]),
+                                                   torch.as_tensor(np.eye(case.A)[action][None]))
+        tree = search.expand(tree, node, action, sim + 1, lg.numpy(), nh.numpy(), rew.numpy(), val.numpy(), ntp)
+        tree = search.backward(tree, sim + 1, ntp)
+    return tree
+
+
+def test_step_by_step_api_reproduces_reference_tree(mcts_pkg):
+    m, asel, qt, tr = mcts_pkg
+    real_uniform = np.random.uniform
+    for name in ('search_hash_puct.npz', 'search_hash_gumbel.npz'):
+        for case in [c for c in hash_cases(name) if c.S == 10][:3]:
+            calls = {'n': 0}
+
+            def counter_uniform(low=0.0, high=1.0, size=None):
+                row = mznoise.noise_row(case.seed, case.idx, calls['n'], int(size))
+                calls['n'] += 1
+                return row
+            np.random.uniform = counter_uniform
+            try:
+                tree = _step_by_step(m, asel, qt, case)
+            finally:
+                np.random.uniform = real_uniform
+            assert_tree_equal(tree, case)
+            counts, probs, q = tree.summary()
+            assert np.array_equal(counts, case['children_visits'][0])
+
+
+def test_module_level_helpers(mcts_pkg):
+    m, asel, qt, tr = mcts_pkg
+    z = load('misc.npz')
+    assert asel.get_considered_visits(9, 25) == tuple(int(x) for x in z['cv_9_25'])
+    assert tr.Tree.ROOT_INDEX == 0 and tr.Tree.NO_PARENT == -1 and tr.Tree.UNVISITED == -1 and tr.Tree.P1 == 0
+    x = np.array([0.1, 0.9, 0.5])
+    assert asel.masked_argmax(x, np.array([1.0, 0.0, 1.0])) == 2
+    assert asel.masked_argmax(x, None) == 1
+    case = [c for c in hash_cases('search_hash_gumbel.npz') if c.S == 10][0]
+    from oracle import oracle as orc
+    cv = case['children_visits'][3]
+    qv = case['children_rewards'][3] + case.gamma * case['children_values'][3]
+    got = qt.compute_mixed_value(case['node_raw_values'][3], qv, cv, case['children_prior_logits'][3])
+    import ctypes as C
+    ref = np.zeros(case.A)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    orc.lib().orc_compute_mixed_value(C.c_int(case.A), C.c_double(float(case['node_raw_values'][3])),
+                                      p(np.ascontiguousarray(qv)), p(np.ascontiguousarray(cv)),
+                                      p(np.ascontiguousarray(case['children_prior_logits'][3])), p(ref))
+    assert np.array_equal(got, ref)
+
+
+def test_dense_network_batched_search_on_gpu(mcts_pkg):
+    """Real (lowered) networks evaluated on the GPU inside search_batch: structural invariants,
+    and agreement with the reference's recorded search up to fp32 network rounding."""
+    m = mcts_pkg[0]
+    from test_network_lowering import load_net
+    for name, obs_shape in (('mlp_cartpole', (1, 1, 4)), ('resnet_tictactoe', (3, 3, 3))):
+        z, net = load_net(name)
+        net.to('cuda')
+        p = 'r1_'  # a Gumbel case: no tie-break noise involved
+        gumbel, A, S, players, H, to_play, seed, idx, calls = [int(x) for x in z[p + 'meta']]
+        cfg = make_config(gumbel, A, S, players, float(z[p + 'gamma']))
+        B = 8
+        np.random.seed(seed)  # first gumbel draw == the fixture's
+        search = m.MCTS(cfg)
+        obs = np.repeat(z[p + 'obs'][None], B, 0)
+        actions, values, probs = search.search_batch(net, obs, np.repeat(z[p + 'legal'][None], B, 0),
+                                                     np.full(B, to_play))
+        tree = search.last_tree(0)
+        assert tree.node_visits[0] == S + 1 and tree.children_visits[0].sum() == S
+        assert np.array_equal(tree.children_visits[0], z[p + 'children_visits'][0])
+        assert int(actions[0]) == int(z[p + 'action'])
+        assert abs(float(values[0]) - float(z[p + 'search_value'])) < 1e-5
+        np.testing.assert_allclose(probs[0], z[p + 'probs'], atol=1e-4)
+        np.testing.assert_allclose(tree.node_values, z[p + 'node_values'], atol=1e-5)
