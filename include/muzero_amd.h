@@ -35,7 +35,7 @@ extern "C" {
 
 /* Built-in leaf evaluators for the fused search (mz_search_run). */
 #define MZ_NET_HASH 0        /* synthetic hash network (csrc/hashnet.h) */
-#define MZ_NET_MLP 1         /* MuZeroFullyConnectedNetwork, network.py:189-225,405-479 */
+#define MZ_NET_DENSE 1       /* network lowered to a dense program (mz_set_network), weights resident in LDS */
 
 /* The attributes MCTS reads from its config (mcts/mcts.py:27-30,68-69,90,112,162,181-227,236). */
 typedef struct mz_config {
@@ -124,9 +124,19 @@ int mz_expand_backup(mz_ctx *ctx, const float *logits, const double *value, cons
 int mz_to_act(mz_ctx *ctx, double temperature, const double *u, int32_t *out_action,
               double *out_probs, double *out_root_value, double *out_q, void *stream);
 
-/* Fused search: all n_simulations of mcts/mcts.py:236-248 in one launch, leaves evaluated by a
- * built-in network.  net_kind MZ_NET_HASH: params = {logit_shift, reward_on, parent_predicts}
- * (host int32[3]).  Tree must have been reset. */
+/* Uploads a network lowered to a dense program: replaces the weights behind
+ * network.recurrent_inference (network.py:105-126; MuZeroFullyConnectedNetwork :189-225, 405-479, or
+ * MuZeroResidualNetwork :133-186 on a small board).  meta_h int32[n_meta] + data_h float[n_data] in the
+ * level-scheduled layout documented in muzero_amd/packing.py; io_h int32[12] = scratch offsets
+ * {hidden in, action in, next hidden, reward logits, policy logits, value logits} then {H, A,
+ * action encoding size, support size, normalisation groups, observation size}. */
+int mz_set_network(mz_ctx *ctx, const int32_t *meta_h, int32_t n_meta, const float *data_h, int32_t n_data,
+                   const int32_t *io_h);
+
+/* Fused search: all n_simulations of mcts/mcts.py:236-248 in one launch, leaves evaluated inside
+ * the kernel.  net_kind MZ_NET_HASH: net_params_h = host int32[3] {logit_shift, reward_on,
+ * parent_predicts}; MZ_NET_DENSE: the network given to mz_set_network (net_params_h unused), which
+ * must fit in LDS together with the activation scratch.  Tree must have been reset. */
 int mz_search_run(mz_ctx *ctx, int32_t net_kind, const void *net_params_h, const double *noise,
                   int32_t noise_max_calls, void *stream);
 

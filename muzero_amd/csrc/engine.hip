@@ -143,6 +143,123 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int
     }
 }
 
+
+// ---------------------------------------------------------------------------- fused network search
+// Leaf evaluation by a lowered network ("dense program", layout in muzero_amd/packing.py) whose
+// weights fit in LDS: the block stages weights + tables once, every lane group owns an activation
+// scratch in LDS, and a level's output rows are spread over the group's lanes.
+struct NetDev {
+    const int32_t *meta;
+    const float *data;
+    int n_meta, n_data;
+    int io[12];  // in_hidden, in_action, out_next, out_reward, out_policy, out_value, H, A, action_size, support, norm_groups, obs
+};
+
+template <int LANES>
+__device__ __forceinline__ float gminf(float v)
+{
+#pragma unroll
+    for (int m = LANES / 2; m > 0; m >>= 1) { float o = __shfl_xor(v, m, LANES); v = o < v ? o : v; }
+    return v;
+}
+
+// utils/network_utils.py:75-96 over `n` logits held in LDS: float32 softmax, expectation over the
+// integer support in float64, inverse of h(x) = sign(x)(sqrt(|x|+1)-1) + 0.001x.
+template <int LANES>
+__device__ __forceinline__ double support_to_scalar(const float *lg, int n, int a)
+{
+    const int L = (n - 1) / 2;
+    float mx = -__builtin_huge_valf();
+    for (int i = a; i < n; i += LANES) mx = lg[i] > mx ? lg[i] : mx;
+    mx = gmaxf<LANES>(mx);
+    float s = 0.0f;
+    for (int i = a; i < n; i += LANES) s += expf(lg[i] - mx);
+#pragma unroll
+    for (int m = LANES / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, LANES);
+    double x = 0.0;
+    for (int i = a; i < n; i += LANES) x += (double)(expf(lg[i] - mx) / s) * (double)(i - L);
+#pragma unroll
+    for (int m = LANES / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, LANES);
+    const double eps = 0.001;
+    double sg = x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
+    double t = (sqrt(1 + 4 * eps * (fabs(x) + 1 + eps)) - 1) / (2 * eps);
+    return sg * (t * t - 1);
+}
+
+__device__ __forceinline__ void lds_fence()
+{
+    // LDS operations of one wave complete in order; this only stops the compiler from moving them.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int first_leaf, int n_sims,
+                                                          const double *noise, int noise_max_calls,
+                                                          int scratch_floats)
+{
+    extern __shared__ float lds[];
+    float *w = lds;                                                  // [n_data]
+    int32_t *meta = reinterpret_cast<int32_t *>(lds + net.n_data);   // [n_meta]
+    float *scratch0 = lds + net.n_data + net.n_meta;
+    for (int i = threadIdx.x; i < net.n_data; i += MZ_BLOCK) w[i] = net.data[i];
+    for (int i = threadIdx.x; i < net.n_meta; i += MZ_BLOCK) meta[i] = net.meta[i];
+    float *sc = scratch0 + (size_t)(threadIdx.x / LANES) * scratch_floats;
+    for (int i = threadIdx.x % LANES; i < scratch_floats; i += LANES) sc[i] = 0.0f;
+    __syncthreads();
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    const int A = d.L.A, H = d.L.H;
+    bool on = a < A;
+    const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
+    float *hid = d.hidden + (long long)t * d.L.N * H;
+    const int n_levels = meta[0];
+    const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
+    const float *bias = w + meta[4];
+    const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
+    for (int s = 0; s < n_sims; s++) {
+        int leaf = first_leaf + s;
+        int action, ntp, depth;
+        int parent = descend<LANES, GUMBEL>(d, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+        // inputs: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
+        const float *ph = hid + (long long)parent * H;
+        for (int i = a; i < H; i += LANES) sc[net.io[0] + i] = ph[i];
+        for (int i = a; i < asz; i += LANES) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
+        lds_fence();
+        for (int l = 0; l < n_levels; l++) {
+            const int n_rows = lv[4 * l], kmax = lv[4 * l + 1], row0 = lv[4 * l + 3];
+            const float *WT = w + lv[4 * l + 2];
+            for (int r = a; r < n_rows; r += LANES) {
+                const int32_t *ds = rows + 4 * (row0 + r);
+                const float *x = sc + ds[0];
+                float acc = bias[row0 + r];
+                for (int k = 0; k < kmax; k++) acc = fmaf(WT[k * n_rows + r], x[k], acc);
+                if (ds[3] >= 0) acc += sc[ds[3]];
+                if (ds[2] == 1) acc = acc > 0.0f ? acc : 0.0f;
+                else if (ds[2] == 2) acc = acc > 0.0f ? acc : expm1f(acc);
+                sc[ds[1]] = acc;
+            }
+            lds_fence();
+        }
+        // next hidden state: per-group min-max scaling (utils/network_utils.py:132-158), straight to the leaf's slot
+        float *dst = hid + (long long)leaf * H;
+        const int per = H / ngroups;
+        for (int g = 0; g < ngroups; g++) {
+            const float *raw = sc + net.io[2] + g * per;
+            float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+            for (int i = a; i < per; i += LANES) { float v = raw[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+            mn = gminf<LANES>(mn); mx = gmaxf<LANES>(mx);
+            float den = (mx - mn) + 1e-5f;
+            for (int i = a; i < per; i += LANES) dst[g * per + i] = (raw[i] - mn) / den;
+        }
+        double value = support_to_scalar<LANES>(sc + net.io[5], sup, a);
+        double reward = support_to_scalar<LANES>(sc + net.io[3], sup, a);
+        float lg = on ? sc[net.io[4] + a] : 0.0f;
+        expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value, reward);
+        __threadfence_block();
+    }
+}
+
 // mcts/action_selection.py:52-70 (PUCT) / :121-138 (Gumbel) + mcts/tree.py:60-68.
 template <int LANES, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, const double *u,
@@ -316,6 +433,9 @@ struct mz_ctx {
     std::vector<void *> allocs;
     double *node_tmp;   // device scratch for per-node ops [A]
     int32_t *node_act;  // device scratch
+    NetDev net;         // uploaded dense-program network (mz_set_network)
+    int net_scratch;    // activation floats per tree
+    void *net_meta_d, *net_data_d;
 };
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -386,6 +506,7 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     c->cfg.c_table_h = nullptr;
     c->lanes = lanes;
     c->n_expanded = 0; c->selected = 0; c->B = 0;
+    memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_meta_d = c->net_data_d = nullptr;
     Dev &d = c->d;
     memset(&d, 0, sizeof d);
     Layout &L = d.L;
@@ -444,6 +565,8 @@ extern "C" void mz_destroy(mz_ctx *c)
 {
     if (!c) return;
     for (void *p : c->allocs) (void)hipFree(p);
+    if (c->net_meta_d) (void)hipFree(c->net_meta_d);
+    if (c->net_data_d) (void)hipFree(c->net_data_d);
     delete c;
 }
 
@@ -567,15 +690,50 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
     if (rc) return rc;
     if (c->B < 1) return fail(MZ_ERR_STATE, "mz_search_run: no tree (call mz_tree_reset first)");
     if (c->selected) return fail(MZ_ERR_STATE, "mz_search_run: a selection is pending");
-    if (net_kind != MZ_NET_HASH) return fail(MZ_ERR_ARG, "mz_search_run: unsupported net_kind");
-    if (!net_params_h) return fail(MZ_ERR_ARG, "mz_search_run: null network parameters");
-    if (c->cfg.hidden_size < 2) return fail(MZ_ERR_ARG, "mz_search_run: hash network needs hidden_size >= 2");
+    if (net_kind != MZ_NET_HASH && net_kind != MZ_NET_DENSE) return fail(MZ_ERR_ARG, "mz_search_run: unsupported net_kind");
     if ((rc = check_noise(c, noise, noise_max_calls, "mz_search_run"))) return rc;
     if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
-    const int32_t *p = reinterpret_cast<const int32_t *>(net_params_h);
-    HashNet hn{p[0], p[1], p[2]};
     int n_sims = c->cfg.n_simulations - c->n_expanded;
     if (n_sims <= 0) return fail(MZ_ERR_STATE, "mz_search_run: all simulations already done");
+    if (net_kind == MZ_NET_DENSE) {
+        if (!c->net.meta) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network first)");
+        size_t lds = ((size_t)c->net.n_data + c->net.n_meta + (size_t)(MZ_BLOCK / c->lanes) * c->net_scratch) * 4;
+        if (lds > 160 * 1024)
+            return fail(MZ_ERR_ARG, "mz_search_run: network does not fit in LDS for the fused search; use the step API");
+        hipStream_t st_ = (hipStream_t)stream;
+        const bool g_ = c->cfg.gumbel != 0;
+        hipError_t attr_err = hipSuccess;
+        auto launch_ = [&](auto lanes_tag) {
+            constexpr int LN = decltype(lanes_tag)::value;
+            unsigned grid_ = (unsigned)(((long long)c->B * LN + MZ_BLOCK - 1) / MZ_BLOCK);
+            if (g_) {
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_net<LN, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((k_search_net<LN, true>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, c->net,
+                                   c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch);
+            } else {
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_net<LN, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((k_search_net<LN, false>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, c->net,
+                                   c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch);
+            }
+        };
+        switch (c->lanes) {
+        case 2: launch_(std::integral_constant<int, 2>()); break;
+        case 4: launch_(std::integral_constant<int, 4>()); break;
+        case 8: launch_(std::integral_constant<int, 8>()); break;
+        case 16: launch_(std::integral_constant<int, 16>()); break;
+        case 32: launch_(std::integral_constant<int, 32>()); break;
+        default: launch_(std::integral_constant<int, 64>()); break;
+        }
+        if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
+        c->n_expanded += n_sims;
+        return launch_status("mz_search_run");
+    }
+    if (!net_params_h) return fail(MZ_ERR_ARG, "mz_search_run: null network parameters");
+    if (c->cfg.hidden_size < 2) return fail(MZ_ERR_ARG, "mz_search_run: hash network needs hidden_size >= 2");
+    const int32_t *p = reinterpret_cast<const int32_t *>(net_params_h);
+    HashNet hn{p[0], p[1], p[2]};
     MZ_DISPATCH(c, k_search_hash, c->B, stream, c->d, hn, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
     c->n_expanded += n_sims;
     return launch_status("mz_search_run");
@@ -766,4 +924,36 @@ extern "C" int mz_node_backward(mz_ctx *c, int32_t b, int32_t leaf, int32_t to_p
     hipLaunchKernelGGL(k_node_backward, dim3(1), dim3(64), 0, st, c->d, (int)b, (int)leaf, (int)to_play);
     if ((rc = launch_status("mz_node_backward"))) return rc;
     return device_error(c, st, "mz_node_backward");
+}
+
+extern "C" int mz_set_network(mz_ctx *c, const int32_t *meta_h, int32_t n_meta, const float *data_h,
+                              int32_t n_data, const int32_t *io_h)
+{
+    int rc = check_ctx(c, "mz_set_network");
+    if (rc) return rc;
+    if (!meta_h || !data_h || !io_h || n_meta < 8 || n_data < 1) return fail(MZ_ERR_ARG, "mz_set_network: null/empty program");
+    if (meta_h[3] != n_data || meta_h[6] + 4 * meta_h[2] != n_meta) return fail(MZ_ERR_ARG, "mz_set_network: inconsistent program header");
+    if (io_h[6] != c->cfg.hidden_size || io_h[7] != c->cfg.n_actions)
+        return fail(MZ_ERR_ARG, "mz_set_network: network hidden size / action count differ from the context's");
+    if (io_h[10] < 1 || io_h[6] % io_h[10]) return fail(MZ_ERR_ARG, "mz_set_network: hidden size not divisible by normalisation groups");
+    // every row must read and write inside the scratch
+    const int32_t *lv = meta_h + meta_h[5], *rows = meta_h + meta_h[6];
+    for (int l = 0; l < meta_h[0]; l++)
+        for (int r = 0; r < lv[4 * l]; r++) {
+            const int32_t *d = rows + 4 * (lv[4 * l + 3] + r);
+            if (d[0] < 0 || d[0] + lv[4 * l + 1] > meta_h[1] || d[1] < 0 || d[1] >= meta_h[1] || d[3] >= meta_h[1])
+                return fail(MZ_ERR_ARG, "mz_set_network: a row addresses outside the activation scratch");
+        }
+    if (c->net_meta_d) { (void)hipFree(c->net_meta_d); c->net_meta_d = nullptr; }
+    if (c->net_data_d) { (void)hipFree(c->net_data_d); c->net_data_d = nullptr; }
+    HIPCHK(hipMalloc(&c->net_meta_d, (size_t)n_meta * 4));
+    HIPCHK(hipMalloc(&c->net_data_d, (size_t)n_data * 4));
+    HIPCHK(hipMemcpy(c->net_meta_d, meta_h, (size_t)n_meta * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->net_data_d, data_h, (size_t)n_data * 4, hipMemcpyHostToDevice));
+    c->net.meta = reinterpret_cast<const int32_t *>(c->net_meta_d);
+    c->net.data = reinterpret_cast<const float *>(c->net_data_d);
+    c->net.n_meta = n_meta; c->net.n_data = n_data;
+    memcpy(c->net.io, io_h, sizeof c->net.io);
+    c->net_scratch = meta_h[1];
+    return MZ_OK;
 }

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, 'libmuzero_amd.so')
 _lib = None
 
 NOISE_COUNTER, NOISE_BUFFER, NOISE_NONE = 0, 1, 2
-NET_HASH, NET_MLP = 0, 1
+NET_HASH, NET_DENSE = 0, 1
 
 
 class EngineError(RuntimeError):
@@ -41,7 +41,7 @@ class MzTreeHost(C.Structure):
 
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits',
            'mz_version']
 
@@ -68,6 +68,7 @@ def lib():
         L.mz_expand_backup.argtypes = [vp, vp, vp, vp, vp, vp]
         L.mz_to_act.argtypes = [vp, f64, vp, vp, vp, vp, vp, vp]
         L.mz_search_run.argtypes = [vp, i32, vp, vp, i32, vp]
+        L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
         L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
         L.mz_stats.argtypes = [vp, vp, vp, vp]
@@ -231,6 +232,22 @@ class SearchEngine:
             nz = self._dev(noise, torch.float64)
             max_calls = nz.numel() // (self.B * self.A)
         _check(lib().mz_search_run(self._ctx, NET_HASH, params, _ptr(nz), max_calls, _stream()))
+
+    def set_network(self, packed):
+        """Uploads a PackedNetwork (muzero_amd.packing) as the leaf evaluator of `search_net`."""
+        r, io = packed.recurrent, packed.io()
+        self._net_keep = (r, io)
+        _check(lib().mz_set_network(self._ctx, r.meta.ctypes.data_as(C.c_void_p), int(r.meta.size),
+                                    r.data.ctypes.data_as(C.c_void_p), int(r.data.size),
+                                    io.ctypes.data_as(C.c_void_p)))
+
+    def search_net(self, noise=None):
+        """All simulations in one launch, leaves evaluated by the uploaded network."""
+        nz, max_calls = None, 0
+        if noise is not None:
+            nz = self._dev(noise, torch.float64)
+            max_calls = nz.numel() // (self.B * self.A)
+        _check(lib().mz_search_run(self._ctx, NET_DENSE, None, _ptr(nz), max_calls, _stream()))
 
     def to_act(self, temperature=0.0, u=None):
         B = self.B

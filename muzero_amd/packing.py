@@ -1,0 +1,131 @@
+"""Packs dense programs (muzero_amd/network.py) into the flat arrays the HIP kernels and the C
+checker consume.
+
+A program is scheduled into LEVELS: a step's level is one more than the deepest level among the
+producers of its input and skip tensors, so all rows (output neurons) of a level can be computed
+at once from the activation scratch.  Per level the weights are stored TRANSPOSED and zero-padded
+to the level's widest input, ``W_T[k][row]``, so consecutive lanes read consecutive floats.
+
+int32 meta:
+  [0] n_levels   [1] scratch floats per tree   [2] total rows   [3] floats in data   [4] bias offset in data
+  [5] index of the level table in meta          [6] index of the row table in meta    [7] reserved
+  level table, 4 ints per level: n_rows, kmax, weight offset in data, first row
+  row table, 4 ints per row:     input offset, output offset, activation (0 none, 1 relu, 2 elu), skip offset or -1
+float32 data: per level W_T[kmax][n_rows], then the biases of all rows.
+Offsets of inputs/outputs are positions in a tree's activation scratch.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+ACT = {'none': 0, 'relu': 1, 'elu': 2}
+
+
+@dataclass
+class PackedProgram:
+    meta: np.ndarray          # int32
+    data: np.ndarray          # float32
+    slots: Dict[str, int]     # tensor name -> offset in the scratch
+    sizes: Dict[str, int]     # tensor name -> floats
+    macs: int                 # multiply-accumulates per evaluation (unpadded)
+
+    @property
+    def n_levels(self) -> int:
+        return int(self.meta[0])
+
+    @property
+    def scratch(self) -> int:
+        return int(self.meta[1])
+
+    def weight_bytes(self) -> int:
+        return int(self.data.nbytes + self.meta.nbytes)
+
+
+def pack(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = None) -> PackedProgram:
+    """steps: DenseStep list; inputs: name -> size of every external input, laid out first in the
+    scratch in the given order; aliases: name -> (base tensor, offset, size) views of inputs."""
+    aliases = aliases or {}
+    slots: Dict[str, int] = {}
+    sizes: Dict[str, int] = {}
+    level_of: Dict[str, int] = {}
+    off = 0
+    for name, size in inputs.items():
+        slots[name], sizes[name], level_of[name] = off, int(size), 0
+        off += int(size)
+    for name, (base, o, size) in aliases.items():
+        slots[name], sizes[name], level_of[name] = slots[base] + o, int(size), 0
+    levels: List[list] = []
+    for s in steps:
+        N, K = s.W.shape
+        if sizes[s.inp] != K:
+            raise ValueError(f'step {s.out}: input {s.inp} has {sizes[s.inp]} floats, weight expects {K}')
+        lv = 1 + max(level_of[s.inp], level_of[s.skip] if s.skip else 0)
+        level_of[s.out] = lv
+        slots[s.out], sizes[s.out] = off, int(N)
+        off += int(N)
+        while len(levels) < lv:
+            levels.append([])
+        levels[lv - 1].append(s)
+    n_rows = sum(int(s.W.shape[0]) for s in steps)
+    meta = [len(levels), off, n_rows, 0, 0, 8, 8 + 4 * len(levels), 0]
+    level_tab, row_tab, blobs, biases = [], [], [], []
+    w_off, row0, macs = 0, 0, 0
+    for lv in levels:
+        kmax = max(int(s.W.shape[1]) for s in lv)
+        rows = sum(int(s.W.shape[0]) for s in lv)
+        WT = np.zeros((kmax, rows), np.float32)
+        r = 0
+        for s in lv:
+            N, K = s.W.shape
+            WT[:K, r:r + N] = s.W.detach().cpu().numpy().T
+            b = s.b.detach().cpu().numpy()
+            for j in range(N):
+                row_tab += [slots[s.inp], slots[s.out] + j, ACT[s.act], (slots[s.skip] + j) if s.skip else -1]
+                biases.append(b[j])
+            r += N
+            macs += N * K
+        # a row that reads fewer than kmax inputs multiplies the zero padding by whatever follows its
+        # input in the scratch, so the scratch must extend kmax floats past every input offset
+        level_tab += [rows, kmax, w_off, row0]
+        blobs.append(WT.reshape(-1))
+        w_off += WT.size
+        row0 += rows
+    pad = max(level_tab[1::4], default=0)
+    meta[1] = off + pad
+    meta[3] = w_off + len(biases)
+    meta[4] = w_off
+    data = np.concatenate(blobs + [np.asarray(biases, np.float32)]) if blobs else np.zeros(0, np.float32)
+    return PackedProgram(np.asarray(meta + level_tab + row_tab, np.int32), data.astype(np.float32), slots, sizes, macs)
+
+
+@dataclass
+class PackedNetwork:
+    """Everything the engine / checker need to evaluate a lowered MuZero network."""
+    recurrent: PackedProgram   # inputs: hidden[H] + action[action_size]; dynamics and prediction merged
+    represent: PackedProgram   # input: obs
+    predict: PackedProgram     # input: hidden
+    H: int
+    A: int
+    action_size: int
+    obs_size: int
+    support_limit: int
+    norm_groups: int
+
+    def io(self) -> np.ndarray:
+        """int32[12]: scratch offsets of the recurrent program's inputs/outputs and the shape facts."""
+        r = self.recurrent
+        return np.asarray([r.slots['xa'], r.slots['xa'] + self.H, r.slots['next_raw'], r.slots['reward_logits'],
+                           r.slots['policy_logits'], r.slots['value_logits'], self.H, self.A, self.action_size,
+                           2 * self.support_limit + 1, self.norm_groups, self.obs_size], np.int32)
+
+
+def pack_network(net) -> PackedNetwork:
+    """net: muzero_amd.network.MuZeroDenseNetwork."""
+    H, asz = net.H, net.action_size
+    rec = pack(list(net.dyn.steps) + list(net.pred.steps), {'xa': H + asz}, {'hidden': ('xa', 0, H)})
+    rep = pack(net.rep.steps, {'obs': net.obs_size})
+    pred = pack(net.pred.steps, {'hidden': H})
+    return PackedNetwork(rec, rep, pred, H, net.A, asz, net.obs_size, net.support_limit, net.norm_groups)

@@ -677,3 +677,157 @@ void orc_search_batch_hash(const orc_cfg *c, const orc_hashnet *hn, int H, int64
         free(t.children_values); free(t.hidden_states); free(rh);
     }
 }
+
+/* ---------------------------------------------------------------- network leaf evaluation
+ * A lowered MuZero network is a "dense program" (muzero_amd/packing.py documents the flat
+ * layout): levels of rows, each row = one output neuron  act(bias + sum_k W_T[k][row] * x[in+k]
+ * (+ skip)).  For the reference's fully connected network (network.py:405-479,
+ * utils/network_utils.py:8-22: Linear + ELU stacks) this is exactly its forward pass; plain
+ * float32 multiply-adds in k order.  Compared against the reference's own outputs at 1e-5. */
+void orc_dense_run(const int32_t *meta, const float *data, float *scratch)
+{
+    int n_levels = meta[0];
+    const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
+    const float *bias = data + meta[4];
+    for (int l = 0; l < n_levels; l++) {
+        int n_rows = lv[4 * l], kmax = lv[4 * l + 1], w_off = lv[4 * l + 2], row0 = lv[4 * l + 3];
+        const float *WT = data + w_off;
+        for (int r = 0; r < n_rows; r++) {
+            const int32_t *d = rows + 4 * (row0 + r);
+            float acc = bias[row0 + r];
+            for (int k = 0; k < kmax; k++) acc += WT[(size_t)k * n_rows + r] * scratch[d[0] + k];
+            if (d[3] >= 0) acc += scratch[d[3]];
+            if (d[2] == 1) acc = acc > 0 ? acc : 0;
+            else if (d[2] == 2) acc = acc > 0 ? acc : expm1f(acc);
+            scratch[d[1]] = acc;
+        }
+    }
+}
+
+/* utils/network_utils.py:132-158: (s - min) / (max - min + 1e-5) per group, float32. */
+void orc_minmax_norm(const float *in, float *out, int n, int groups)
+{
+    int per = n / groups;
+    for (int g = 0; g < groups; g++) {
+        float mn = in[g * per], mx = in[g * per];
+        for (int i = 1; i < per; i++) {
+            float v = in[g * per + i];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+        float den = (mx - mn) + 1e-5f;
+        for (int i = 0; i < per; i++) out[g * per + i] = (in[g * per + i] - mn) / den;
+    }
+}
+
+/* utils/network_utils.py:75-96: float32 softmax . arange(-L..L) in float64, inverse value transform. */
+double orc_support_to_scalar(const float *logits, int n)
+{
+    int L = (n - 1) / 2;
+    float mx = logits[0];
+    for (int i = 1; i < n; i++) if (logits[i] > mx) mx = logits[i];
+    float e[1024], s = 0;
+    for (int i = 0; i < n; i++) { e[i] = expf(logits[i] - mx); s += e[i]; }
+    double x = 0;
+    for (int i = 0; i < n; i++) x += (double)(e[i] / s) * (double)(i - L);
+    const double eps = 0.001;
+    double sg = x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
+    double t = (sqrt(1 + 4 * eps * (fabs(x) + 1 + eps)) - 1) / (2 * eps);
+    return sg * (t * t - 1);
+}
+
+/* io = PackedNetwork.io(): {in_hidden, in_action, out_next, out_reward, out_policy, out_value, H, A,
+ * action_size, support, norm_groups, obs_size}.  recurrent_inference of network.py:105-126. */
+void orc_net_recurrent(const int32_t *meta, const float *data, const int32_t *io, const float *hidden,
+                       int action, float *scratch, float *logits_out, float *next_hidden_out,
+                       double *value_out, double *reward_out)
+{
+    int H = io[6], A = io[7], asz = io[8], sup = io[9];
+    memset(scratch, 0, sizeof(float) * meta[1]);
+    memcpy(scratch + io[0], hidden, sizeof(float) * H);
+    for (int i = 0; i < asz; i++) scratch[io[1] + i] = i == action ? 1.0f : 0.0f;
+    orc_dense_run(meta, data, scratch);
+    orc_minmax_norm(scratch + io[2], next_hidden_out, H, io[10]);
+    memcpy(logits_out, scratch + io[4], sizeof(float) * A);
+    *value_out = orc_support_to_scalar(scratch + io[5], sup);
+    *reward_out = orc_support_to_scalar(scratch + io[3], sup);
+}
+
+void orc_net_recurrent_batch(const int32_t *meta, const float *data, const int32_t *io, int64_t B,
+                             const float *hidden, const int32_t *action, float *logits_out,
+                             float *next_hidden_out, double *value_out, double *reward_out)
+{
+    int H = io[6], A = io[7];
+    float *scratch = malloc(sizeof(float) * meta[1]);
+    for (int64_t b = 0; b < B; b++)
+        orc_net_recurrent(meta, data, io, hidden + b * H, action[b], scratch, logits_out + b * A,
+                          next_hidden_out + b * H, value_out + b, reward_out + b);
+    free(scratch);
+}
+
+/*
+ * B independent searches with a packed network as the leaf evaluator (the CPU baseline of the
+ * benchmark): roots are given already evaluated (root_logits f32[B][A], root_hidden f32[B][H],
+ * root_value f64[B]) -- the one initial inference per search is outside the loop this times.
+ */
+void orc_search_batch_net(const orc_cfg *c, const int32_t *meta, const float *data, const int32_t *io,
+                          int64_t B, const float *root_logits, const float *root_hidden,
+                          const double *root_value, const double *legal, const int32_t *to_play,
+                          const double *dirichlet, double frac, const double *gumbel, uint64_t seed,
+                          uint64_t tree_id0, int32_t *out_root_visits, double *out_root_value,
+                          int64_t *out_node_visits, int32_t *out_action, int n_threads)
+{
+    int N = c->S + 1, A = c->A, H = io[6];
+#pragma omp parallel num_threads(n_threads)
+    {
+        orc_tree t;
+        memset(&t, 0, sizeof t);
+        t.H = H;
+        t.node_visits = malloc(sizeof(int32_t) * N); t.node_values = malloc(sizeof(double) * N);
+        t.node_raw_values = malloc(sizeof(double) * N); t.parents = malloc(sizeof(int32_t) * N);
+        t.action_from_parent = malloc(sizeof(int32_t) * N); t.to_play = malloc(sizeof(int32_t) * N);
+        t.children_index = malloc(sizeof(int32_t) * N * A);
+        t.children_prior_logits = malloc(sizeof(double) * N * A);
+        t.children_visits = malloc(sizeof(int32_t) * N * A);
+        t.children_rewards = malloc(sizeof(double) * N * A);
+        t.children_values = malloc(sizeof(double) * N * A);
+        t.hidden_states = malloc(sizeof(float) * (size_t)N * H);
+        float *scratch = malloc(sizeof(float) * meta[1]);
+        float *nh = malloc(sizeof(float) * H);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t b = 0; b < B; b++) {
+            float pf[ORC_MAX_A], lg[ORC_MAX_A];
+            double pd[ORC_MAX_A], probs[ORC_MAX_A];
+            t.root_legal = legal + b * A;
+            t.gumbel_noise = c->gumbel ? gumbel + b * A : NULL;
+            if (c->gumbel) {
+                orc_gumbel_root_prior(A, root_logits + b * A, t.root_legal, pf);
+                orc_tree_init(c, &t, pf, root_value[b], root_hidden + b * H, to_play[b]);
+            } else {
+                orc_puct_root_prior(A, root_logits + b * A, dirichlet + b * A, frac, t.root_legal, pd);
+                orc_tree_init(c, &t, pd, root_value[b], root_hidden + b * H, to_play[b]);
+            }
+            orc_noise nz; memset(&nz, 0, sizeof nz); nz.seed = seed; nz.tree_id = tree_id0 + b;
+            for (int sim = 0; sim < c->S; sim++) {
+                int action, ntp, depth;
+                int node = simulate(c, &t, &nz, &action, &ntp, &depth);
+                double value, reward;
+                orc_net_recurrent(meta, data, io, t.hidden_states + (size_t)node * H, action, scratch, lg, nh,
+                                  &value, &reward);
+                orc_expand(c, &t, node, action, sim + 1, lg, nh, reward, value, ntp);
+                orc_backward(c, &t, sim + 1, ntp);
+            }
+            int64_t nvs = 0;
+            for (int n = 0; n < N; n++) nvs += t.node_visits[n];
+            out_node_visits[b] = nvs - 1;
+            out_root_value[b] = t.node_values[0];
+            for (int a = 0; a < A; a++) out_root_visits[b * A + a] = t.children_visits[a];
+            if (c->gumbel) out_action[b] = orc_gumbel_to_act(c, &t, probs, NULL);
+            else out_action[b] = orc_puct_to_act(c, &t, 0.0, 0.0, probs, NULL);
+        }
+        free(t.node_visits); free(t.node_values); free(t.node_raw_values); free(t.parents);
+        free(t.action_from_parent); free(t.to_play); free(t.children_index);
+        free(t.children_prior_logits); free(t.children_visits); free(t.children_rewards);
+        free(t.children_values); free(t.hidden_states); free(scratch); free(nh);
+    }
+}

@@ -246,3 +246,38 @@ def search_batch_hash(config, hash_params, H, root_codes, legal, to_play, dirich
                                 _p(tp), _p(di), C.c_double(frac), _p(gu), C.c_uint64(seed),
                                 C.c_uint64(tree_id0), _p(rv), _p(val), _p(nv), _p(act), C.c_int(n_threads))
     return SimpleNamespace(root_visits=rv, root_value=val, node_visits=nv, action=act)
+
+
+def net_recurrent_batch(packed, hidden, actions):
+    """Leaf evaluation of a packed network (muzero_amd.packing.PackedNetwork) on the host."""
+    r = packed.recurrent
+    hidden = np.ascontiguousarray(hidden, np.float32)
+    B = hidden.shape[0]
+    act = np.ascontiguousarray(actions, np.int32)
+    io = packed.io()
+    lg, nh = np.zeros((B, packed.A), np.float32), np.zeros((B, packed.H), np.float32)
+    val, rew = np.zeros(B), np.zeros(B)
+    lib().orc_net_recurrent_batch(_p(r.meta), _p(r.data), _p(io), C.c_int64(B), _p(hidden), _p(act), _p(lg),
+                                  _p(nh), _p(val), _p(rew))
+    return lg, nh, val, rew
+
+
+def search_batch_net(config, packed, root_logits, root_hidden, root_value, legal, to_play, dirichlet=None,
+                     frac=0.0, gumbel=None, seed=0, tree_id0=0, n_threads=1, c_table=None):
+    """B independent searches with a packed network as leaf evaluator, on host threads."""
+    o = Oracle(config, 0, c_table)
+    rl = np.ascontiguousarray(root_logits, np.float32)
+    B, A = rl.shape
+    rh = np.ascontiguousarray(root_hidden, np.float32).reshape(B, -1)
+    rv0 = np.ascontiguousarray(root_value, np.float64)
+    lg = np.ascontiguousarray(legal, np.float64)
+    tp = np.ascontiguousarray(to_play, np.int32)
+    di = None if dirichlet is None else np.ascontiguousarray(dirichlet, np.float64)
+    gu = None if gumbel is None else np.ascontiguousarray(gumbel, np.float64)
+    rv, val = np.zeros((B, A), np.int32), np.zeros(B)
+    nv, act = np.zeros(B, np.int64), np.zeros(B, np.int32)
+    r, io = packed.recurrent, packed.io()
+    lib().orc_search_batch_net(C.byref(o.cfg), _p(r.meta), _p(r.data), _p(io), C.c_int64(B), _p(rl), _p(rh),
+                               _p(rv0), _p(lg), _p(tp), _p(di), C.c_double(frac), _p(gu), C.c_uint64(seed),
+                               C.c_uint64(tree_id0), _p(rv), _p(val), _p(nv), _p(act), C.c_int(n_threads))
+    return SimpleNamespace(root_visits=rv, root_value=val, node_visits=nv, action=act)

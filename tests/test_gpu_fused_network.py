@@ -1,0 +1,101 @@
+"""GPU: the fused search whose leaves are evaluated in-kernel by a lowered network.
+
+Network outputs on the GPU (fma chains, device expf/expm1f) differ from the host's in the last
+bits, so trees are compared the way the north star states it: visit counts identical for
+(nearly) every tree, values within 1e-5; the bit-exact checks given identical network outputs
+live in test_gpu_tree_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_config
+from test_network_lowering import load_net, net_config
+from muzero_amd.packing import pack_network
+from muzero_amd.network import MuZeroNetwork
+
+pytestmark = pytest.mark.gpu
+
+
+def _roots(net, B, obs_shape, rng):
+    obs = rng.uniform(-0.05, 0.05, size=(B,) + obs_shape).astype(np.float32)
+    logits, hidden, value = net.initial_inference(torch.as_tensor(obs))
+    return obs, logits.numpy(), hidden.numpy().reshape(B, -1), value.numpy()
+
+
+@pytest.mark.parametrize('gumbel', [False, True])
+def test_fused_mlp_search_vs_checker(gumbel):
+    from muzero_amd.engine import SearchEngine
+    from oracle import oracle as orc
+    z, net = load_net('mlp_cartpole')
+    packed = pack_network(net)
+    B, A, S = 1024, 2, 50
+    rng = np.random.default_rng(3)
+    cfg = make_config(gumbel, A, S, 1, 0.997)
+    obs, logits, hidden, value = _roots(net, B, (1, 1, 4), rng)
+    legal = np.ones((B, A))
+    tp = np.zeros(B, np.int32)
+    g = rng.gumbel(size=(B, A)) if gumbel else None
+    di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
+    ref = orc.search_batch_net(cfg, packed, logits, hidden, value, legal, tp, dirichlet=di, frac=0.25, gumbel=g,
+                               seed=5, tree_id0=0, n_threads=8)
+    for lanes in (2, 8, 64):
+        eng = SearchEngine(cfg, packed.H, B, seed=5, lanes_per_tree=lanes)
+        eng.set_network(packed)
+        prior = eng.root_prepare(logits, legal, di, 0.25)
+        eng.reset(prior, value, hidden, tp, legal, g)
+        eng.search_net()
+        action, root_value, probs, _ = eng.to_act(0.0)
+        nv, _ = eng.stats()
+        visits = np.stack([eng.export_tree(b)['children_visits'][0] for b in range(0, B, 8)])
+        same = (visits == ref.root_visits[::8]).all(axis=1)
+        assert same.mean() >= 0.98, (lanes, same.mean())
+        rv = root_value.cpu().numpy()
+        close = np.abs(rv - ref.root_value) < 1e-5
+        assert close.mean() >= 0.98, (lanes, close.mean())
+        assert (action.cpu().numpy() == ref.action).mean() >= 0.98
+        assert abs(int(nv.sum()) - int(ref.node_visits.sum())) <= 0.01 * ref.node_visits.sum()
+        eng.close()
+
+
+def test_fused_equals_step_mode_with_torch_network():
+    """Same trees whether leaves are evaluated inside the fused kernel or by torch between the
+    select and expand kernels (both on the GPU)."""
+    from muzero_amd.engine import SearchEngine
+    z, net = load_net('mlp_cartpole')
+    packed = pack_network(net)
+    B, A, S = 256, 2, 50
+    rng = np.random.default_rng(4)
+    cfg = make_config(False, A, S, 1, 0.997)
+    obs, logits, hidden, value = _roots(net, B, (1, 1, 4), rng)
+    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    di = rng.dirichlet([0.25] * A, size=B)
+    gnet = MuZeroNetwork(net_config('mlp_cartpole'), net.state_dict()).to('cuda')
+    eng = SearchEngine(cfg, packed.H, B, seed=9)
+    eng.set_network(packed)
+    prior = eng.root_prepare(logits, legal, di, 0.25)
+    eng.reset(prior, value, hidden, tp, legal)
+    eng.search_net()
+    a1, v1, p1, _ = eng.to_act(0.0)
+    eng.reset(prior, value, hidden, tp, legal)
+    for _ in range(S):
+        parent, action, phid = eng.select()
+        lg, nh, val, rew = gnet.recurrent_flat(phid, gnet.encode_actions(action))
+        eng.expand_backup(lg, val, rew, nh)
+    a2, v2, p2, _ = eng.to_act(0.0)
+    assert (a1 == a2).float().mean() >= 0.98
+    assert ((v1 - v2).abs() < 1e-5).float().mean() >= 0.98
+    eng.close()
+
+
+def test_network_too_large_for_lds_is_rejected():
+    from muzero_amd.engine import SearchEngine
+    z, net = load_net('resnet_tictactoe')
+    packed = pack_network(net)
+    cfg = make_config(True, 9, 10, 2, 1)
+    eng = SearchEngine(cfg, packed.H, 4)
+    eng.set_network(packed)
+    eng.reset(np.zeros((2, 9), np.float32), np.zeros(2), np.zeros((2, packed.H), np.float32), np.zeros(2, np.int32),
+              np.ones((2, 9)), np.zeros((2, 9)))
+    with pytest.raises(ValueError):
+        eng.search_net()
+    eng.close()

@@ -97,3 +97,20 @@ def test_random_state_dict_has_reference_names_and_shapes():
         for k in ref:
             assert tuple(sd[k].shape) == tuple(ref[k]), k
         MuZeroNetwork(net_config(name), sd)  # compiles
+
+
+@pytest.mark.parametrize('name', ['mlp_cartpole', 'mlp_synthetic', 'resnet_tictactoe'])
+def test_packed_program_checker_matches_reference_outputs(name):
+    """The packed (level-scheduled, transposed) form of the network, run by the C checker, against
+    the reference modules' recorded outputs."""
+    from muzero_amd.packing import pack_network
+    from oracle import oracle as orc
+    z, net = load_net(name)
+    packed = pack_network(net)
+    assert packed.recurrent.macs == net.recurrent_macs()
+    hid = z['init_hidden'].reshape(len(z['actions']), -1)
+    lg, nh, val, rew = orc.net_recurrent_batch(packed, hid, z['actions'])
+    np.testing.assert_allclose(lg, z['rec_logits'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(nh, z['rec_hidden'].reshape(nh.shape), atol=HTOL, rtol=0)
+    np.testing.assert_allclose(val, z['rec_value'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(rew, z['rec_reward'], atol=TOL, rtol=0)
