@@ -1,0 +1,213 @@
+"""Benchmark of the batched MCTS search (BASELINE.json metric: MCTS simulations/sec).
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3h|cfg4s|cfg5h]
+
+One process per GPU (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE).  A step is one full batched
+search over the rank's trees with inputs resident in HBM: root inference + root preparation
+(1 launch), all simulations with in-kernel leaf evaluation (1 launch), final action rule
+(1 launch).  Weak scaling: every rank searches its own B trees; there is no data-path collective.
+
+Default workload = BASELINE.json configs[1]: CartPole, 256 envs x 50 simulations, PUCT,
+random-init MuZeroFullyConnectedNetwork (encoding 8, hidden layers [16], support 21).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from muzero_amd import distributed as mzdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def cartpole_net_config():
+    return SimpleNamespace(network='mlp', observation_dim=[1, 1, 4], n_actions=2, n_stacked_observations=1,
+                           encoding_size=8, fc_reward_layers=[16], fc_policy_layers=[16], fc_value_layers=[16],
+                           fc_representation_layers=[], fc_hidden_state_layers=[16], support_limit=10)
+
+
+def search_config(gumbel, A, S, players, gamma):
+    return SimpleNamespace(simulations=S, n_actions=A, gamma=gamma, players=players, gumbel=gumbel,
+                           max_considered_actions=16, gumbel_scale=1.0, c_visit=50, c_scale=1.0,
+                           c_base=19625, c_init=1.25, dirichlet_alpha=0.25, exploration_frac=0.25)
+
+
+WORKLOADS = {
+    # name: (description, gumbel, A, S, players, gamma, B per GPU, leaf evaluator)
+    'cfg2': ('CartPole 256 envs x 50 sims PUCT, random-init MLP (BASELINE configs[1])', False, 2, 50, 1, 0.997, 256, 'mlp'),
+    'cfg4s': ('CartPole 8192 envs x 50 sims PUCT search only, random-init MLP (configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'mlp'),
+    'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
+    'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
+}
+
+
+def algorithmic_bytes(node_visits_total, B, S, A, H, gumbel):
+    """HBM bytes the tree work of one search needs, from the per-unit figures of the design:
+    per selection level 36 + 6w + A(4 + p + 2w), per expansion 8H + pA + 20 + 3w, with the stored
+    widths w = 8 (values/rewards) and p = 8 (PUCT priors) / 4 (Gumbel priors).  The number of
+    selection levels is sum over simulations of the leaf depth = node_visits - B*S."""
+    w, p = 8, (4 if gumbel else 8)
+    levels = node_visits_total - B * S
+    return levels * (36 + 6 * w + A * (4 + p + 2 * w)) + B * S * (8 * H + p * A + 20 + 3 * w)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lanes', type=int, default=0)
+    args = ap.parse_args()
+
+    rank, world = mzdist.init()
+    _, local_rank, _ = mzdist.env_rank_world()
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.network import MuZeroNetwork
+    from muzero_amd.packing import pack_network
+    from muzero_amd import hashnet
+
+    desc, gumbel, A, S, players, gamma, B, leaf = WORKLOADS[args.workload]
+    cfg = search_config(gumbel, A, S, players, gamma)
+    rng = np.random.default_rng(1 + rank)
+    tree_id0 = rank * B
+    packed = None
+    if leaf == 'mlp':
+        torch.manual_seed(0)
+        net = MuZeroNetwork(cartpole_net_config(), seed=0)
+        packed = pack_network(net)
+        H = packed.H
+        eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
+        eng.set_network(packed)
+        obs = torch.as_tensor(rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32), device=dev)
+    else:
+        H = 144 if A == 9 else 256
+        eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
+        hp = hashnet.HashNetParams(A, H, 4, 1, 1)
+        codes = rng.integers(0, 2**32, size=B, dtype=np.uint64).astype(np.uint32)
+        hid = np.zeros((B, H), np.float32)
+        hid[:, 0], hid[:, 1] = codes & 0xFFFF, codes >> 16
+        root_hidden = torch.as_tensor(hid, device=dev)
+        root_logits = torch.as_tensor(rng.standard_normal((B, A)).astype(np.float32), device=dev)
+        root_value = torch.zeros(B, dtype=torch.float64, device=dev)
+    legal = torch.ones((B, A), dtype=torch.uint8, device=dev)
+    to_play = torch.zeros(B, dtype=torch.int32, device=dev)
+    dirichlet = None if gumbel else torch.as_tensor(rng.dirichlet([0.25] * A, size=B), device=dev)
+    gnoise = torch.as_tensor(rng.gumbel(size=(B, A)), device=dev) if gumbel else None
+    u = torch.as_tensor(rng.random(B), device=dev)
+    temperature = 1.0
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if leaf == 'mlp':
+            eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
+        else:
+            prior = eng.root_prepare(root_logits, legal, dirichlet, 0.25)
+            eng.reset(prior, root_value, root_hidden, to_play, legal, gnoise, tree_id0=tree_id0)
+        if i is not None:
+            ev[i][0].record()
+        if leaf == 'mlp':
+            eng.search_net()
+        else:
+            eng.search_hash(4, 1, 1)
+        if i is not None:
+            ev[i][1].record()
+        return eng.to_act(temperature, u)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    mzdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    mzdist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = mzdist.max_over_ranks(elapsed, dev if world > 1 else 'cpu')
+
+    nv, _ = eng.stats()
+    node_visits = int(nv.sum().item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    alg = algorithmic_bytes(node_visits, B, S, A, H, gumbel)
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+    sims = world * B * S * args.steps
+    nv_all = mzdist.sum_over_ranks(node_visits, dev if world > 1 else 'cpu')
+
+    out = {
+        'metric': 'MCTS simulations/sec', 'value': sims / elapsed, 'unit': 'simulations/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic', 'config': {'workload': desc, 'trees_per_gpu': B, 'simulations': S, 'n_actions': A,
+                                        'rule': 'gumbel' if gumbel else 'puct', 'leaf_eval': leaf,
+                                        'lanes_per_tree': eng and int(args.lanes)},
+        'node_visits_per_sec': nv_all * args.steps / elapsed,
+        'mean_leaf_depth': node_visits / (B * S) - 1.0,
+        'roofline': {'bound': 'hbm', 'kernel': 'k_search_net' if leaf == 'mlp' else 'k_search_hash',
+                     'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': None, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, packed, leaf, A, S, H, B, gumbel)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(cfg, packed, leaf, A, S, H, B, gumbel, budget_s=8.0):
+    """The CPU checker (oracle/, a C port of the reference's search) timed on this box's host
+    cores on the same workload: whole batches repeated until the time budget is used."""
+    from oracle import oracle as orc
+    from muzero_amd import hashnet
+    from muzero_amd.network import MuZeroNetwork
+    threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or min(16, os.cpu_count() or 1)
+    threads = max(1, min(threads, 16))
+    rng = np.random.default_rng(1)
+    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
+    g = rng.gumbel(size=(B, A)) if gumbel else None
+    if leaf == 'mlp':
+        net = MuZeroNetwork(cartpole_net_config(), seed=0)
+        obs = rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32)
+        lg, hid, val = net.initial_inference(torch.as_tensor(obs))
+        run = lambda: orc.search_batch_net(cfg, packed, lg.numpy(), hid.numpy(), val.numpy(), legal, tp, dirichlet=di,  # noqa: E731
+                                           frac=0.25, gumbel=g, seed=0, n_threads=threads)
+    else:
+        hp = hashnet.HashNetParams(A, H, 4, 1, 1)
+        n = min(B, 2048)
+        codes = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+        B = n
+        run = lambda: orc.search_batch_hash(cfg, hp, H, codes, legal[:n], tp[:n], dirichlet=None if di is None else di[:n],  # noqa: E731
+                                            frac=0.25, gumbel=None if g is None else g[:n], seed=0, n_threads=threads)
+    run()
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        r = run()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {'value': reps * B * S / dt, 'unit': 'simulations/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{reps} batches of {B} trees x {S} sims ({dt:.1f} s), one tree per OpenMP thread',
+            'node_visits_per_sec': reps * float(r.node_visits.sum()) / dt}
+
+
+if __name__ == '__main__':
+    main()

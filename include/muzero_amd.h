@@ -133,6 +133,24 @@ int mz_to_act(mz_ctx *ctx, double temperature, const double *u, int32_t *out_act
 int mz_set_network(mz_ctx *ctx, const int32_t *meta_h, int32_t n_meta, const float *data_h, int32_t n_data,
                    const int32_t *io_h);
 
+/* Uploads the representation and prediction programs behind network.initial_inference
+ * (network.py:86-103).  io_h int32[8] = {obs offset in the representation scratch, raw hidden offset in it,
+ * hidden offset in the prediction scratch, policy logits offset, value logits offset, observation
+ * floats, support size, normalisation groups}. */
+int mz_set_root_network(mz_ctx *ctx, const int32_t *rep_meta_h, int32_t rep_n_meta, const float *rep_data_h,
+                        int32_t rep_n_data, const int32_t *pred_meta_h, int32_t pred_n_meta,
+                        const float *pred_data_h, int32_t pred_n_data, const int32_t *io_h);
+
+/* Replaces the head of MCTS.search (mcts/mcts.py:176-235) for B observations in one launch:
+ * initial_inference, add_exploration_noise / Gumbel noise, mask_illegal_action_logits and
+ * initialize_tree.  obs f32[B][obs floats]; legal u8[B][A]; to_play i32[B]; dirichlet f64[B][A] (PUCT)
+ * or gumbel f64[B][A] (Gumbel); out_logits f32[B][A] / out_value f64[B] optional copies of the raw
+ * network outputs. */
+int mz_search_begin_net(mz_ctx *ctx, int32_t B, const float *obs, const uint8_t *legal,
+                        const int32_t *to_play, const double *dirichlet, double exploration_frac,
+                        const double *gumbel, uint64_t tree_id0, float *out_logits, double *out_value,
+                        void *stream);
+
 /* Fused search: all n_simulations of mcts/mcts.py:236-248 in one launch, leaves evaluated inside
  * the kernel.  net_kind MZ_NET_HASH: net_params_h = host int32[3] {logit_shift, reward_on,
  * parent_predicts}; MZ_NET_DENSE: the network given to mz_set_network (net_params_h unused), which

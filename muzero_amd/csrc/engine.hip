@@ -27,6 +27,39 @@ __device__ __forceinline__ bool group_ids(const Dev &d, int *t, int *a)
 }
 
 // Root rows + per-tree search state (mcts/mcts.py:93-96 on top of the lazily initialised storage).
+// `prior` is this lane's prepared root prior logit, `is_legal` this lane's legality.
+template <int LANES, bool GUMBEL>
+__device__ __forceinline__ void write_root(const Dev &d, int t, int a, bool on, double prior, double val,
+                                           int to_play, bool is_legal, double gumbel_a, int max_considered)
+{
+    RowView w = view(d, t, 0);
+    if (a == 0) {
+        NodeHdr h;
+        h.visits = 1; h.parent = -1; h.afp = -1; h.to_play = to_play; h.value = val; h.raw = val;
+        *w.hdr = h;
+        d.noise_calls[t] = 0;
+        d.visit_total[t] = 0;
+        d.sel_depth[t] = -1;
+    }
+    unsigned long long mask = __ballot(on && is_legal);
+    int sh = (int)((threadIdx.x % 64) / LANES) * LANES;  // this group's lanes inside the 64-bit ballot
+    mask = LANES == 64 ? mask : (mask >> sh) & ((1ull << LANES) - 1ull);
+    if (on) {
+        w.cval[a] = 0.0; w.crew[a] = 0.0; w.cvis[a] = 0; w.cidx[a] = -1;
+        if (GUMBEL) {
+            reinterpret_cast<float *>(w.prior)[a] = (float)prior;
+            d.gumbel[(long long)t * d.L.A + a] = gumbel_a;
+        } else {
+            reinterpret_cast<double *>(w.prior)[a] = prior;
+        }
+    }
+    if (a == 0) {
+        d.legal[t] = mask;
+        int n_legal = __popcll(mask);
+        d.m_considered[t] = max_considered < n_legal ? max_considered : n_legal;
+    }
+}
+
 template <int LANES, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_reset(Dev d, const void *root_prior, const double *root_value,
                                                      const float *root_hidden, const int32_t *root_to_play,
@@ -37,34 +70,15 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_reset(Dev d, const void *root_prio
     if (!group_ids<LANES>(d, &t, &a)) return;
     const int A = d.L.A;
     bool on = a < A;
-    RowView w = view(d, t, 0);
-    double val = root_value[t];
-    if (a == 0) {
-        NodeHdr h;
-        h.visits = 1; h.parent = -1; h.afp = -1; h.to_play = root_to_play[t]; h.value = val; h.raw = val;
-        *w.hdr = h;
-        d.noise_calls[t] = 0;
-        d.visit_total[t] = 0;
-        d.sel_depth[t] = -1;
-    }
-    bool lg = on && legal[(long long)t * A + a] != 0;
-    unsigned long long mask = __ballot(lg);
-    int sh = (int)((threadIdx.x % 64) / LANES) * LANES;  // this group's lanes inside the 64-bit ballot
-    mask = LANES == 64 ? mask : (mask >> sh) & ((1ull << LANES) - 1ull);
+    long long k = (long long)t * A + a;
+    double prior = 0.0, g = 0.0;
     if (on) {
-        w.cval[a] = 0.0; w.crew[a] = 0.0; w.cvis[a] = 0; w.cidx[a] = -1;
-        if (GUMBEL) {
-            reinterpret_cast<float *>(w.prior)[a] = reinterpret_cast<const float *>(root_prior)[(long long)t * A + a];
-            d.gumbel[(long long)t * A + a] = gumbel[(long long)t * A + a];
-        } else {
-            reinterpret_cast<double *>(w.prior)[a] = reinterpret_cast<const double *>(root_prior)[(long long)t * A + a];
-        }
+        prior = GUMBEL ? (double)reinterpret_cast<const float *>(root_prior)[k]
+                       : reinterpret_cast<const double *>(root_prior)[k];
+        if (GUMBEL) g = gumbel[k];
     }
-    if (a == 0) {
-        d.legal[t] = mask;
-        int n_legal = __popcll(mask);
-        d.m_considered[t] = max_considered < n_legal ? max_considered : n_legal;
-    }
+    write_root<LANES, GUMBEL>(d, t, a, on, prior, root_value[t], root_to_play[t], on && legal[k] != 0, g,
+                              max_considered);
     if (root_hidden) {
         float *dst = d.hidden + (long long)t * d.L.N * d.L.H;
         for (int i = a; i < d.L.H; i += LANES) dst[i] = root_hidden[(long long)t * d.L.H + i];
@@ -193,6 +207,102 @@ __device__ __forceinline__ void lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// One evaluation of a dense program by a lane group: rows of a level are spread over the lanes.
+template <int LANES>
+__device__ __forceinline__ void dense_run(const int32_t *meta, const float *w, float *sc, int a)
+{
+    const int n_levels = meta[0];
+    const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
+    const float *bias = w + meta[4];
+    for (int l = 0; l < n_levels; l++) {
+        const int n_rows = lv[4 * l], kmax = lv[4 * l + 1], row0 = lv[4 * l + 3];
+        const float *WT = w + lv[4 * l + 2];
+        for (int r = a; r < n_rows; r += LANES) {
+            const int32_t *ds = rows + 4 * (row0 + r);
+            const float *x = sc + ds[0];
+            float acc = bias[row0 + r];
+            for (int k = 0; k < kmax; k++) acc = fmaf(WT[k * n_rows + r], x[k], acc);
+            if (ds[3] >= 0) acc += sc[ds[3]];
+            if (ds[2] == 1) acc = acc > 0.0f ? acc : 0.0f;
+            else if (ds[2] == 2) acc = acc > 0.0f ? acc : expm1f(acc);
+            sc[ds[1]] = acc;
+        }
+        lds_fence();
+    }
+}
+
+// utils/network_utils.py:132-158: per-group min-max scaling of `raw` (LDS) into `dst` (and `dst2` if given).
+template <int LANES>
+__device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, int a, float *dst, float *dst2)
+{
+    const int per = H / ngroups;
+    for (int g = 0; g < ngroups; g++) {
+        const float *r = raw + g * per;
+        float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+        for (int i = a; i < per; i += LANES) { float v = r[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        mn = gminf<LANES>(mn); mx = gmaxf<LANES>(mx);
+        float den = (mx - mn) + 1e-5f;
+        for (int i = a; i < per; i += LANES) {
+            float v = (r[i] - mn) / den;
+            dst[g * per + i] = v;
+            if (dst2) dst2[g * per + i] = v;
+        }
+    }
+}
+
+// Root of a search evaluated on the device: initial_inference (network.py:86-103: representation,
+// normalisation, prediction, support_to_scalar) + root prior preparation + the root rows.
+struct RootNetDev {
+    const int32_t *rep_meta, *pred_meta;
+    const float *rep_data, *pred_data;
+    int rep_n_meta, rep_n_data, pred_n_meta, pred_n_data;
+    int rep_scratch, pred_scratch;
+    int obs_off, raw_off, hid_off, pol_off, val_off, obs_size, support, ngroups;
+};
+
+template <int LANES, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_begin_net(Dev d, RootNetDev rn, const float *obs,
+                                                         const uint8_t *legal, const int32_t *to_play,
+                                                         const double *dirichlet, double frac,
+                                                         const double *gumbel, int max_considered,
+                                                         float *out_logits, double *out_value)
+{
+    extern __shared__ float lds[];
+    float *rw = lds;
+    int32_t *rm = reinterpret_cast<int32_t *>(rw + rn.rep_n_data);
+    float *pw = reinterpret_cast<float *>(rm + rn.rep_n_meta);
+    int32_t *pm = reinterpret_cast<int32_t *>(pw + rn.pred_n_data);
+    float *scratch0 = reinterpret_cast<float *>(pm + rn.pred_n_meta);
+    for (int i = threadIdx.x; i < rn.rep_n_data; i += MZ_BLOCK) rw[i] = rn.rep_data[i];
+    for (int i = threadIdx.x; i < rn.rep_n_meta; i += MZ_BLOCK) rm[i] = rn.rep_meta[i];
+    for (int i = threadIdx.x; i < rn.pred_n_data; i += MZ_BLOCK) pw[i] = rn.pred_data[i];
+    for (int i = threadIdx.x; i < rn.pred_n_meta; i += MZ_BLOCK) pm[i] = rn.pred_meta[i];
+    const int per_group = rn.rep_scratch + rn.pred_scratch;
+    float *sr = scratch0 + (size_t)(threadIdx.x / LANES) * per_group, *sp = sr + rn.rep_scratch;
+    for (int i = threadIdx.x % LANES; i < per_group; i += LANES) sr[i] = 0.0f;
+    __syncthreads();
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    const int A = d.L.A, H = d.L.H;
+    bool on = a < A;
+    for (int i = a; i < rn.obs_size; i += LANES) sr[rn.obs_off + i] = obs[(long long)t * rn.obs_size + i];
+    lds_fence();
+    dense_run<LANES>(rm, rw, sr, a);
+    minmax_to<LANES>(sr + rn.raw_off, H, rn.ngroups, a, d.hidden + (long long)t * d.L.N * H, sp + rn.hid_off);
+    lds_fence();
+    dense_run<LANES>(pm, pw, sp, a);
+    double value = support_to_scalar<LANES>(sp + rn.val_off, rn.support, a);
+    float lg = on ? sp[rn.pol_off + a] : 0.0f;
+    long long k = (long long)t * A + a;
+    bool lgl = on && legal[k] != 0;
+    double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
+    double pr = root_prior<LANES, GUMBEL>(lg, on, lgl, di, frac, a, A, true);
+    write_root<LANES, GUMBEL>(d, t, a, on, pr, value, to_play[t], lgl, (GUMBEL && on) ? gumbel[k] : 0.0,
+                              max_considered);
+    if (out_logits && on) out_logits[k] = lg;
+    if (out_value && a == 0) out_value[t] = value;
+}
+
 template <int LANES, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int first_leaf, int n_sims,
                                                           const double *noise, int noise_max_calls,
@@ -213,9 +323,6 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     bool on = a < A;
     const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
     float *hid = d.hidden + (long long)t * d.L.N * H;
-    const int n_levels = meta[0];
-    const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
-    const float *bias = w + meta[4];
     const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
@@ -226,32 +333,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         for (int i = a; i < H; i += LANES) sc[net.io[0] + i] = ph[i];
         for (int i = a; i < asz; i += LANES) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
         lds_fence();
-        for (int l = 0; l < n_levels; l++) {
-            const int n_rows = lv[4 * l], kmax = lv[4 * l + 1], row0 = lv[4 * l + 3];
-            const float *WT = w + lv[4 * l + 2];
-            for (int r = a; r < n_rows; r += LANES) {
-                const int32_t *ds = rows + 4 * (row0 + r);
-                const float *x = sc + ds[0];
-                float acc = bias[row0 + r];
-                for (int k = 0; k < kmax; k++) acc = fmaf(WT[k * n_rows + r], x[k], acc);
-                if (ds[3] >= 0) acc += sc[ds[3]];
-                if (ds[2] == 1) acc = acc > 0.0f ? acc : 0.0f;
-                else if (ds[2] == 2) acc = acc > 0.0f ? acc : expm1f(acc);
-                sc[ds[1]] = acc;
-            }
-            lds_fence();
-        }
-        // next hidden state: per-group min-max scaling (utils/network_utils.py:132-158), straight to the leaf's slot
-        float *dst = hid + (long long)leaf * H;
-        const int per = H / ngroups;
-        for (int g = 0; g < ngroups; g++) {
-            const float *raw = sc + net.io[2] + g * per;
-            float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
-            for (int i = a; i < per; i += LANES) { float v = raw[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-            mn = gminf<LANES>(mn); mx = gmaxf<LANES>(mx);
-            float den = (mx - mn) + 1e-5f;
-            for (int i = a; i < per; i += LANES) dst[g * per + i] = (raw[i] - mn) / den;
-        }
+        dense_run<LANES>(meta, w, sc, a);
+        minmax_to<LANES>(sc + net.io[2], H, ngroups, a, hid + (long long)leaf * H, nullptr);
         double value = support_to_scalar<LANES>(sc + net.io[5], sup, a);
         double reward = support_to_scalar<LANES>(sc + net.io[3], sup, a);
         float lg = on ? sc[net.io[4] + a] : 0.0f;
@@ -317,7 +400,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, 
     if (a == 0) { out_action[t] = action; out_root_value[t] = s.nval; }
 }
 
-// mcts/mcts.py:22-31 + utils/game_utils.py:71-78.
+// mcts/mcts.py:22-31 + utils/game_utils.py:71-78 for B roots (root_prior in tree_ops.h).
 template <int LANES, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const float *logits,
                                                             const double *dirichlet, double frac,
@@ -330,20 +413,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const f
     long long k = (long long)gid * A + a;
     float lg = on ? logits[k] : 0.0f;
     bool lgl = on && (legal ? legal[k] != 0 : true);
-    if constexpr (GUMBEL) {
-        float mx = gmaxf<LANES>(on ? lg : -__builtin_huge_valf());
-        if (on) reinterpret_cast<float *>(out)[k] = lgl ? lg - mx : -3.4028234663852886e38f;
-    } else {
-        float e = on ? np_expf(lg) : 0.0f;
-        float es = gsum_np<LANES, float>(e, a, A);
-        float p = __fdiv_rn(e, es);
-        float keep = (float)(1.0 - frac);
-        double noised = (double)(keep * p) + frac * (on ? dirichlet[k] : 0.0);
-        const double tiny = 2.2250738585072014e-308;
-        double l = log(noised > tiny ? noised : tiny);
-        double mx = gmax<LANES>(on ? l : -__builtin_huge_val());
-        if (!shift_and_mask) { if (on) reinterpret_cast<double *>(out)[k] = l; return; }
-        if (on) reinterpret_cast<double *>(out)[k] = lgl ? l - mx : -1.7976931348623157e308;
+    double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
+    double pr = root_prior<LANES, GUMBEL>(lg, on, lgl, di, frac, a, A, shift_and_mask != 0);
+    if (on) {
+        if (GUMBEL) reinterpret_cast<float *>(out)[k] = (float)pr;
+        else reinterpret_cast<double *>(out)[k] = pr;
     }
 }
 
@@ -436,6 +510,8 @@ struct mz_ctx {
     NetDev net;         // uploaded dense-program network (mz_set_network)
     int net_scratch;    // activation floats per tree
     void *net_meta_d, *net_data_d;
+    RootNetDev root;    // representation + prediction programs (mz_set_root_network)
+    void *root_bufs[4];
 };
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -507,6 +583,7 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     c->lanes = lanes;
     c->n_expanded = 0; c->selected = 0; c->B = 0;
     memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_meta_d = c->net_data_d = nullptr;
+    memset(&c->root, 0, sizeof c->root); memset(c->root_bufs, 0, sizeof c->root_bufs);
     Dev &d = c->d;
     memset(&d, 0, sizeof d);
     Layout &L = d.L;
@@ -567,6 +644,7 @@ extern "C" void mz_destroy(mz_ctx *c)
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->net_meta_d) (void)hipFree(c->net_meta_d);
     if (c->net_data_d) (void)hipFree(c->net_data_d);
+    for (void *p : c->root_bufs) if (p) (void)hipFree(p);
     delete c;
 }
 
@@ -956,4 +1034,92 @@ extern "C" int mz_set_network(mz_ctx *c, const int32_t *meta_h, int32_t n_meta, 
     memcpy(c->net.io, io_h, sizeof c->net.io);
     c->net_scratch = meta_h[1];
     return MZ_OK;
+}
+
+static int check_program(const int32_t *meta_h, int32_t n_meta, const float *data_h, int32_t n_data, const char *fn)
+{
+    if (!meta_h || !data_h || n_meta < 8 || n_data < 1) return fail(MZ_ERR_ARG, std::string(fn) + ": null/empty program");
+    if (meta_h[3] != n_data || meta_h[6] + 4 * meta_h[2] != n_meta) return fail(MZ_ERR_ARG, std::string(fn) + ": inconsistent program header");
+    const int32_t *lv = meta_h + meta_h[5], *rows = meta_h + meta_h[6];
+    for (int l = 0; l < meta_h[0]; l++)
+        for (int r = 0; r < lv[4 * l]; r++) {
+            const int32_t *d = rows + 4 * (lv[4 * l + 3] + r);
+            if (d[0] < 0 || d[0] + lv[4 * l + 1] > meta_h[1] || d[1] < 0 || d[1] >= meta_h[1] || d[3] >= meta_h[1])
+                return fail(MZ_ERR_ARG, std::string(fn) + ": a row addresses outside the activation scratch");
+        }
+    return MZ_OK;
+}
+
+extern "C" int mz_set_root_network(mz_ctx *c, const int32_t *rep_meta_h, int32_t rep_n_meta, const float *rep_data_h,
+                                   int32_t rep_n_data, const int32_t *pred_meta_h, int32_t pred_n_meta,
+                                   const float *pred_data_h, int32_t pred_n_data, const int32_t *io_h)
+{
+    int rc = check_ctx(c, "mz_set_root_network");
+    if (rc) return rc;
+    if (!io_h) return fail(MZ_ERR_ARG, "mz_set_root_network: null io");
+    if ((rc = check_program(rep_meta_h, rep_n_meta, rep_data_h, rep_n_data, "mz_set_root_network"))) return rc;
+    if ((rc = check_program(pred_meta_h, pred_n_meta, pred_data_h, pred_n_data, "mz_set_root_network"))) return rc;
+    if (io_h[7] < 1 || c->cfg.hidden_size % io_h[7]) return fail(MZ_ERR_ARG, "mz_set_root_network: bad normalisation groups");
+    for (void *&p : c->root_bufs) if (p) { (void)hipFree(p); p = nullptr; }
+    const void *src[4] = {rep_meta_h, rep_data_h, pred_meta_h, pred_data_h};
+    size_t n[4] = {(size_t)rep_n_meta, (size_t)rep_n_data, (size_t)pred_n_meta, (size_t)pred_n_data};
+    for (int i = 0; i < 4; i++) {
+        HIPCHK(hipMalloc(&c->root_bufs[i], n[i] * 4));
+        HIPCHK(hipMemcpy(c->root_bufs[i], src[i], n[i] * 4, hipMemcpyHostToDevice));
+    }
+    RootNetDev &r = c->root;
+    r.rep_meta = (const int32_t *)c->root_bufs[0]; r.rep_data = (const float *)c->root_bufs[1];
+    r.pred_meta = (const int32_t *)c->root_bufs[2]; r.pred_data = (const float *)c->root_bufs[3];
+    r.rep_n_meta = rep_n_meta; r.rep_n_data = rep_n_data; r.pred_n_meta = pred_n_meta; r.pred_n_data = pred_n_data;
+    r.rep_scratch = rep_meta_h[1]; r.pred_scratch = pred_meta_h[1];
+    r.obs_off = io_h[0]; r.raw_off = io_h[1]; r.hid_off = io_h[2]; r.pol_off = io_h[3]; r.val_off = io_h[4];
+    r.obs_size = io_h[5]; r.support = io_h[6]; r.ngroups = io_h[7];
+    return MZ_OK;
+}
+
+extern "C" int mz_search_begin_net(mz_ctx *c, int32_t B, const float *obs, const uint8_t *legal,
+                                   const int32_t *to_play, const double *dirichlet, double frac,
+                                   const double *gumbel, uint64_t tree_id0, float *out_logits,
+                                   double *out_value, void *stream)
+{
+    int rc = check_ctx(c, "mz_search_begin_net");
+    if (rc) return rc;
+    if (!c->root.rep_meta) return fail(MZ_ERR_STATE, "mz_search_begin_net: no root network (call mz_set_root_network first)");
+    if (B < 1 || B > c->cfg.max_batch) return fail(MZ_ERR_ARG, "mz_search_begin_net: B outside 1..max_batch");
+    if (!obs || !legal || !to_play) return fail(MZ_ERR_ARG, "mz_search_begin_net: null argument");
+    if (c->cfg.gumbel ? !gumbel : !dirichlet) return fail(MZ_ERR_ARG, "mz_search_begin_net: root noise missing");
+    const RootNetDev &r = c->root;
+    size_t lds = ((size_t)r.rep_n_data + r.rep_n_meta + r.pred_n_data + r.pred_n_meta +
+                  (size_t)(MZ_BLOCK / c->lanes) * (r.rep_scratch + r.pred_scratch)) * 4;
+    if (lds > 160 * 1024) return fail(MZ_ERR_ARG, "mz_search_begin_net: root network does not fit in LDS");
+    c->B = B; c->d.B = B; c->d.tree_id0 = tree_id0;
+    c->n_expanded = 0; c->selected = 0;
+    hipStream_t st_ = (hipStream_t)stream;
+    const bool g_ = c->cfg.gumbel != 0;
+    hipError_t attr_err = hipSuccess;
+    auto launch_ = [&](auto lanes_tag) {
+        constexpr int LN = decltype(lanes_tag)::value;
+        unsigned grid_ = (unsigned)(((long long)B * LN + MZ_BLOCK - 1) / MZ_BLOCK);
+        if (g_) {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_begin_net<LN, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_begin_net<LN, true>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, r, obs, legal,
+                               to_play, dirichlet, frac, gumbel, (int)c->cfg.max_considered_actions, out_logits, out_value);
+        } else {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_begin_net<LN, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_begin_net<LN, false>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, r, obs, legal,
+                               to_play, dirichlet, frac, gumbel, (int)c->cfg.max_considered_actions, out_logits, out_value);
+        }
+    };
+    switch (c->lanes) {
+    case 2: launch_(std::integral_constant<int, 2>()); break;
+    case 4: launch_(std::integral_constant<int, 4>()); break;
+    case 8: launch_(std::integral_constant<int, 8>()); break;
+    case 16: launch_(std::integral_constant<int, 16>()); break;
+    case 32: launch_(std::integral_constant<int, 32>()); break;
+    default: launch_(std::integral_constant<int, 64>()); break;
+    }
+    if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_begin_net: could not raise the dynamic LDS limit");
+    return launch_status("mz_search_begin_net");
 }

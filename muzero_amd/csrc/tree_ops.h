@@ -248,4 +248,27 @@ __device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool o
     if (a == 0) d.visit_total[t] += depth + 1;
 }
 
+// mcts/mcts.py:22-31 + utils/game_utils.py:71-78: this lane's prepared root prior logit from the
+// network's float32 logit (Dirichlet mix in float64 for PUCT, shift by the max, illegal -> dtype min).
+template <int LANES, bool GUMBEL>
+__device__ __forceinline__ double root_prior(float lg, bool on, bool lgl, double dirichlet_a, double frac,
+                                             int a, int A, bool shift_and_mask)
+{
+    if constexpr (GUMBEL) {
+        float mx = gmaxf<LANES>(on ? lg : -__builtin_huge_valf());
+        return (double)(lgl ? lg - mx : -3.4028234663852886e38f);
+    } else {
+        float e = on ? np_expf(lg) : 0.0f;
+        float es = gsum_np<LANES, float>(e, a, A);
+        float p = __fdiv_rn(e, es);
+        float keep = (float)(1.0 - frac);
+        double noised = (double)(keep * p) + frac * (on ? dirichlet_a : 0.0);
+        const double tiny = 2.2250738585072014e-308;
+        double l = log(noised > tiny ? noised : tiny);
+        double mx = gmax<LANES>(on ? l : -__builtin_huge_val());
+        if (!shift_and_mask) return l;
+        return lgl ? l - mx : -1.7976931348623157e308;
+    }
+}
+
 }  // namespace mz

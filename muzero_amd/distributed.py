@@ -1,0 +1,76 @@
+"""Multi-GPU sharding of a batch of independent trees (one process per GPU).
+
+Trees never exchange data during a search, so ranks only agree on who owns which trees
+(block partition, global tree ids keep the counter-based noise independent of the GPU count)
+and, for self-play, gather each step's root statistics on the replay rank.  Works with any
+torch.distributed backend ("nccl" = RCCL over xGMI on MI355X, "gloo" on CPU in the tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)),
+            int(os.environ.get('WORLD_SIZE', 1)))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int]:
+    """Joins the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of the trees rank owns: contiguous blocks, remainder to the first ranks."""
+    base, rem = divmod(int(n_total), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device='cpu') -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device='cpu') -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_root_stats(action: torch.Tensor, root_value: torch.Tensor, probs: torch.Tensor, dst: int = 0):
+    """Gathers each rank's (action i32[b], root_value f64[b], probs f64[b, A]) on `dst`, in rank
+    order (= global tree order for equal shards).  One packed all_gather: latency-bound, a few KB
+    to a few hundred KB per step.  Returns the concatenated tensors on `dst`, None elsewhere."""
+    if not dist.is_initialized():
+        return action, root_value, probs
+    b, A = probs.shape
+    packed = torch.cat([action.to(torch.float64).reshape(b, 1), root_value.reshape(b, 1), probs], dim=1).contiguous()
+    out = [torch.empty_like(packed) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, packed)
+    if dist.get_rank() != dst:
+        return None
+    full = torch.cat(out, dim=0)
+    return full[:, 0].to(torch.int32), full[:, 1].contiguous(), full[:, 2:].contiguous()

@@ -41,7 +41,7 @@ class MzTreeHost(C.Structure):
 
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits',
            'mz_version']
 
@@ -69,6 +69,8 @@ def lib():
         L.mz_to_act.argtypes = [vp, f64, vp, vp, vp, vp, vp, vp]
         L.mz_search_run.argtypes = [vp, i32, vp, vp, i32, vp]
         L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
+        L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
+        L.mz_search_begin_net.argtypes = [vp, i32, vp, vp, vp, vp, f64, vp, u64, vp, vp, vp]
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
         L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
         L.mz_stats.argtypes = [vp, vp, vp, vp]
@@ -241,6 +243,39 @@ class SearchEngine:
                                     r.data.ctypes.data_as(C.c_void_p), int(r.data.size),
                                     io.ctypes.data_as(C.c_void_p)))
 
+        rp, pp = packed.represent, packed.predict
+        rio = np.asarray([rp.slots['obs'], rp.slots['hidden_raw'], pp.slots['hidden'], pp.slots['policy_logits'],
+                          pp.slots['value_logits'], packed.obs_size, 2 * packed.support_limit + 1,
+                          packed.norm_groups], np.int32)
+        self._root_keep = (rp, pp, rio)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _check(lib().mz_set_root_network(self._ctx, vp(rp.meta), int(rp.meta.size), vp(rp.data), int(rp.data.size),
+                                         vp(pp.meta), int(pp.meta.size), vp(pp.data), int(pp.data.size), vp(rio)))
+        self.obs_size = packed.obs_size
+
+    def begin_net(self, obs, legal, to_play, dirichlet=None, exploration_frac=0.0, gumbel=None, tree_id0=0,
+                  want_outputs=False):
+        """Root of B searches in one launch: initial inference, root-prior preparation, root rows."""
+        ob = self._dev(obs, torch.float32)
+        B = ob.shape[0]
+        ob = ob.reshape(B, self.obs_size)
+        le = legal if (torch.is_tensor(legal) and legal.dtype == torch.uint8 and legal.device == self.device) else \
+            self._dev(np.asarray(legal) != 0 if not torch.is_tensor(legal) else legal != 0, torch.uint8, (B, self.A))
+        tp = self._dev(to_play, torch.int32).reshape(B)
+        di = None if dirichlet is None else self._dev(dirichlet, torch.float64, (B, self.A))
+        gu = None if gumbel is None else self._dev(gumbel, torch.float64, (B, self.A))
+        ol = torch.empty((B, self.A), dtype=torch.float32, device=self.device) if want_outputs else None
+        ov = torch.empty(B, dtype=torch.float64, device=self.device) if want_outputs else None
+        _check(lib().mz_search_begin_net(self._ctx, B, _ptr(ob), _ptr(le), _ptr(tp), _ptr(di),
+                                         float(exploration_frac), _ptr(gu), C.c_uint64(int(tree_id0)),
+                                         _ptr(ol), _ptr(ov), _stream()))
+        self.B = B
+        if self._parent is None or self._parent.shape[0] != B:
+            self._parent = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._action = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._phid = torch.empty((B, self.H), dtype=torch.float32, device=self.device) if self.H else None
+        return ol, ov
+
     def search_net(self, noise=None):
         """All simulations in one launch, leaves evaluated by the uploaded network."""
         nz, max_calls = None, 0
@@ -252,10 +287,12 @@ class SearchEngine:
     def to_act(self, temperature=0.0, u=None):
         B = self.B
         uu = None if u is None else self._dev(u, torch.float64).reshape(B)
-        action = torch.empty(B, dtype=torch.int32, device=self.device)
-        probs = torch.empty((B, self.A), dtype=torch.float64, device=self.device)
-        value = torch.empty(B, dtype=torch.float64, device=self.device)
-        q = torch.empty((B, self.A), dtype=torch.float64, device=self.device)
+        if getattr(self, '_act_out', None) is None or self._act_out[0].shape[0] != B:
+            self._act_out = (torch.empty(B, dtype=torch.int32, device=self.device),
+                             torch.empty(B, dtype=torch.float64, device=self.device),
+                             torch.empty((B, self.A), dtype=torch.float64, device=self.device),
+                             torch.empty((B, self.A), dtype=torch.float64, device=self.device))
+        action, value, probs, q = self._act_out
         _check(lib().mz_to_act(self._ctx, float(temperature), _ptr(uu), _ptr(action), _ptr(probs), _ptr(value),
                                _ptr(q), _stream()))
         return action, value, probs, q

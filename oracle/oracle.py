@@ -20,7 +20,7 @@ def build(force: bool = False) -> str:
     so = os.path.join(_HERE, 'liboracle.so')
     src = os.path.join(_HERE, 'mcts_oracle.c')
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(['make', '-C', _HERE, 'liboracle.so'])
+        subprocess.check_call(['make', '-C', _HERE] + (['-B'] if force else []) + ['liboracle.so'])
     return so
 
 
