@@ -44,6 +44,7 @@ struct Dev {
     const double *c_table;    // [S + 2]
     int32_t *err;           // device error flag
     int B, players, noise_mode;
+    int RL;                 // lanes of a group that hold actions: smallest power of two >= A (>= 2)
     double discount, c_visit, c_scale;
     unsigned long long seed, tree_id0;
 };
@@ -54,85 +55,188 @@ __device__ __forceinline__ char *node_rec(const Dev &d, int t, int n)
 }
 
 // ----------------------------------------------------------------- group collectives
+// Cross-lane movement inside a row of 16 lanes uses DPP modifiers (register-to-register, a few
+// cycles); only the two widest butterfly steps (lanes 16 and 32 apart) go through ds_bpermute.
+// W is the number of lanes that take part (a power of two <= LANES, uniform over the wave);
+// lanes >= W of a group must not rely on the result.
+#define MZ_DPP_XOR1 0xB1         // quad_perm:[1,0,3,2]
+#define MZ_DPP_XOR2 0x4E         // quad_perm:[2,3,0,1]
+#define MZ_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8 lanes
+#define MZ_DPP_MIRROR 0x140      // lane i <-> 15-i inside each 16 lanes
+#define MZ_DPP_SHL(n) (0x100 + (n))  // lane i <- lane i+n inside the row
+#define MZ_DPP_SHR(n) (0x110 + (n))  // lane i <- lane i-n inside the row
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);  // no valid source lane: keep own value
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = dpp_mov<CTRL>((int)b), hi = dpp_mov<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// Butterfly partner of step K (pairs blocks of 2^K lanes).  Steps 2 and 3 mirror instead of xor-ing;
+// after the narrower steps every block is uniform, so any lane of the partner block serves.
+template <int K, typename T>
+__device__ __forceinline__ T partner(T v)
+{
+    if constexpr (K == 0) return dpp_mov<MZ_DPP_XOR1>(v);
+    else if constexpr (K == 1) return dpp_mov<MZ_DPP_XOR2>(v);
+    else if constexpr (K == 2) return dpp_mov<MZ_DPP_HALF_MIRROR>(v);
+    else if constexpr (K == 3) return dpp_mov<MZ_DPP_MIRROR>(v);
+    else if constexpr (K == 4) return __shfl_xor(v, 16, 64);
+    else return __shfl_xor(v, 32, 64);
+}
+
+template <int LANES, typename T, typename F>
+__device__ __forceinline__ T greduce(T v, int W, F f)
+{
+    if constexpr (LANES > 1) { if (W > 1) v = f(v, partner<0>(v)); }
+    if constexpr (LANES > 2) { if (W > 2) v = f(v, partner<1>(v)); }
+    if constexpr (LANES > 4) { if (W > 4) v = f(v, partner<2>(v)); }
+    if constexpr (LANES > 8) { if (W > 8) v = f(v, partner<3>(v)); }
+    if constexpr (LANES > 16) { if (W > 16) v = f(v, partner<4>(v)); }
+    if constexpr (LANES > 32) { if (W > 32) v = f(v, partner<5>(v)); }
+    return v;
+}
+
 template <int LANES, typename T>
 __device__ __forceinline__ T gshfl(T v, int src) { return __shfl(v, src, LANES); }
 
 template <int LANES>
-__device__ __forceinline__ double gmin(double v)
+__device__ __forceinline__ double gmin(double v, int W = LANES)
 {
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) { double o = __shfl_xor(v, m, LANES); v = o < v ? o : v; }
-    return v;
+    return greduce<LANES>(v, W, [](double x, double y) { return y < x ? y : x; });
 }
 template <int LANES>
-__device__ __forceinline__ double gmax(double v)
+__device__ __forceinline__ double gmax(double v, int W = LANES)
 {
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) { double o = __shfl_xor(v, m, LANES); v = o > v ? o : v; }
-    return v;
+    return greduce<LANES>(v, W, [](double x, double y) { return y > x ? y : x; });
 }
 template <int LANES>
-__device__ __forceinline__ float gmaxf(float v)
+__device__ __forceinline__ float gmaxf(float v, int W = LANES)
 {
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) { float o = __shfl_xor(v, m, LANES); v = o > v ? o : v; }
-    return v;
+    return greduce<LANES>(v, W, [](float x, float y) { return y > x ? y : x; });
 }
 template <int LANES>
-__device__ __forceinline__ int gmaxi(int v)
+__device__ __forceinline__ float gminf(float v, int W = LANES)
 {
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) { int o = __shfl_xor(v, m, LANES); v = o > v ? o : v; }
-    return v;
+    return greduce<LANES>(v, W, [](float x, float y) { return y < x ? y : x; });
 }
 template <int LANES>
-__device__ __forceinline__ int gsumi(int v)
+__device__ __forceinline__ int gmaxi(int v, int W = LANES)
 {
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, LANES);
-    return v;
+    return greduce<LANES>(v, W, [](int x, int y) { return y > x ? y : x; });
+}
+template <int LANES>
+__device__ __forceinline__ int gsumi(int v, int W = LANES)
+{
+    return greduce<LANES>(v, W, [](int x, int y) { return x + y; });
+}
+template <int LANES>
+__device__ __forceinline__ float gsumf_any(float v, int W = LANES)  // order-free float sum (tolerance paths only)
+{
+    return greduce<LANES>(v, W, [](float x, float y) { return x + y; });
+}
+template <int LANES>
+__device__ __forceinline__ double gsumd_any(double v, int W = LANES)
+{
+    return greduce<LANES>(v, W, [](double x, double y) { return x + y; });
 }
 
 // First maximal index over the group (np.argmax tie rule); `idx` must be >= A on idle lanes.
 template <int LANES>
-__device__ __forceinline__ int gargmax(double v, int idx)
+__device__ __forceinline__ int gargmax(double v, int idx, int W = LANES)
 {
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) {
-        double ov = __shfl_xor(v, m, LANES);
-        int oi = __shfl_xor(idx, m, LANES);
-        bool take = (ov > v) || (ov == v && oi < idx);
-        v = take ? ov : v;
-        idx = take ? oi : idx;
+#define MZ_ARGMAX_STEP(K)                                         \
+    {                                                             \
+        double ov = partner<K>(v);                                \
+        int oi = partner<K>(idx);                                 \
+        bool take = (ov > v) || (ov == v && oi < idx);            \
+        v = take ? ov : v;                                        \
+        idx = take ? oi : idx;                                    \
     }
+    if constexpr (LANES > 1) { if (W > 1) MZ_ARGMAX_STEP(0) }
+    if constexpr (LANES > 2) { if (W > 2) MZ_ARGMAX_STEP(1) }
+    if constexpr (LANES > 4) { if (W > 4) MZ_ARGMAX_STEP(2) }
+    if constexpr (LANES > 8) { if (W > 8) MZ_ARGMAX_STEP(3) }
+    if constexpr (LANES > 16) { if (W > 16) MZ_ARGMAX_STEP(4) }
+    if constexpr (LANES > 32) { if (W > 32) MZ_ARGMAX_STEP(5) }
+#undef MZ_ARGMAX_STEP
     return idx;
+}
+
+// Lane 0's value to lanes 0..W-1 of the group (W <= 16, group aligned inside a row).
+template <typename T>
+__device__ __forceinline__ T bcast0_row(T v, int a, int W)
+{
+    if (W == 2) return dpp_mov<0xA0>(v);  // quad_perm:[0,0,2,2]
+    v = dpp_mov<0x00>(v);                 // quad_perm:[0,0,0,0]
+    if (W > 4) { T t = dpp_mov<MZ_DPP_SHR(4)>(v); v = (a & 4) ? t : v; }
+    if (W > 8) { T t = dpp_mov<MZ_DPP_SHR(8)>(v); v = (a & 8) ? t : v; }
+    return v;
 }
 
 // np.sum over the A values held one per lane, in NumPy's summation order
 // (numpy/_core/src/umath/loops_utils.h.src pairwise_sum: sequential below 8 elements; otherwise 8
 // strided accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail in order).
-// Float addition is commutative, so the xor butterfly over lanes 0..7 reproduces that tree exactly.
-template <int LANES, typename T>
+// Float addition is commutative, so a butterfly over lanes 0..7 reproduces that tree exactly.
+// RL = lanes holding actions (power of two, RL/2 < A <= RL, A >= 1); the result reaches all RL lanes.
+// Up to 16 actions everything stays in DPP: lane 0 accumulates in order, pulling lane i with
+// row_shl:i, and the sum is broadcast back.
+template <int RL, typename T>
 __device__ __forceinline__ T gsum_np(T x, int a, int A)
 {
-    if (A < 8) {
-        T res = (T)(-0.0);
-        for (int i = 0; i < A; i++) res += gshfl<LANES>(x, i);
-        return res;
+#define MZ_PULL(i)                                                                  \
+    if constexpr ((i) < RL) {                                                       \
+        if ((i) < RL / 2 || A > (i)) res += dpp_mov<MZ_DPP_SHL((i) < 16 ? (i) : 1)>(x); \
     }
-    if constexpr (LANES >= 8) {
+    if constexpr (RL <= 4) {
+        T res = x;
+        MZ_PULL(1) MZ_PULL(2) MZ_PULL(3)
+        return bcast0_row(res, a, RL);
+    } else if constexpr (RL == 8) {
+        T res;
+        if (A < 8) {
+            res = x;
+            MZ_PULL(1) MZ_PULL(2) MZ_PULL(3) MZ_PULL(4) MZ_PULL(5) MZ_PULL(6)
+        } else {
+            res = x;
+            res += partner<0>(res);
+            res += partner<1>(res);
+            res += partner<2>(res);
+        }
+        return bcast0_row(res, a, RL);
+    } else if constexpr (RL == 16) {
+        T r = x;
+        if (A == 16) r += dpp_mov<MZ_DPP_SHL(8)>(x);
+        r += partner<0>(r);
+        r += partner<1>(r);
+        r += partner<2>(r);
+        T res = r;
+        if (A < 16) { MZ_PULL(8) MZ_PULL(9) MZ_PULL(10) MZ_PULL(11) MZ_PULL(12) MZ_PULL(13) MZ_PULL(14) }
+        return bcast0_row(res, a, RL);
+    } else {
         const int lim = A - (A % 8);
         T r = x;
-        for (int i = 8; i < lim; i += 8) r += gshfl<LANES>(x, a + i);
-        r += __shfl_xor(r, 1, LANES);
-        r += __shfl_xor(r, 2, LANES);
-        r += __shfl_xor(r, 4, LANES);
-        T res = gshfl<LANES>(r, 0);
-        for (int i = lim; i < A; i++) res += gshfl<LANES>(x, i);
+        for (int i = 8; i < lim; i += 8) r += __shfl(x, a + i, RL);
+        r += partner<0>(r);
+        r += partner<1>(r);
+        r += partner<2>(r);
+        T res = __shfl(r, 0, RL);
+        for (int i = lim; i < A; i++) res += __shfl(x, i, RL);
         return res;
-    } else {
-        return x;  // unreachable: LANES >= A
     }
+#undef MZ_PULL
 }
 
 // ----------------------------------------------------------------- NumPy float32 exp
@@ -169,12 +273,20 @@ __device__ __host__ __forceinline__ unsigned long long splitmix64(unsigned long 
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+__device__ __host__ __forceinline__ unsigned long long noise_key(unsigned long long seed, unsigned long long tree)
+{
+    return splitmix64(seed ^ (tree * 0xD6E8FEB86659FD93ull));
+}
+__device__ __host__ __forceinline__ double noise_from_key(unsigned long long key, unsigned long long call,
+                                                          unsigned action)
+{
+    unsigned long long z = splitmix64(key + call * 64 + action);
+    return (double)(z >> 11) * 0x1p-53;
+}
 __device__ __host__ __forceinline__ double noise_u(unsigned long long seed, unsigned long long tree,
                                                    unsigned long long call, unsigned action)
 {
-    unsigned long long key = splitmix64(seed ^ (tree * 0xD6E8FEB86659FD93ull));
-    unsigned long long z = splitmix64(key + call * 64 + action);
-    return (double)(z >> 11) * 0x1p-53;
+    return noise_from_key(noise_key(seed, tree), call, action);
 }
 
 // ----------------------------------------------------------------- hash network

@@ -17,6 +17,19 @@ using namespace mz;
 
 #define MZ_BLOCK 256
 
+#define MZ_CT_LDS 512  // exploration-constant entries staged in LDS (covers n_simulations <= 510)
+
+// Copies the PUCT exploration-constant table into LDS (all threads of the block, before any exits).
+template <bool GUMBEL>
+__device__ __forceinline__ const double *stage_c_table(const Dev &d, double *lds_ct)
+{
+    if constexpr (GUMBEL) return nullptr;
+    if (d.L.S + 2 > MZ_CT_LDS) return nullptr;
+    for (int i = threadIdx.x; i < d.L.S + 2; i += blockDim.x) lds_ct[i] = d.c_table[i];
+    __syncthreads();
+    return lds_ct;
+}
+
 template <int LANES>
 __device__ __forceinline__ bool group_ids(const Dev &d, int *t, int *a)
 {
@@ -43,7 +56,7 @@ __device__ __forceinline__ void write_root(const Dev &d, int t, int a, bool on, 
     }
     unsigned long long mask = __ballot(on && is_legal);
     int sh = (int)((threadIdx.x % 64) / LANES) * LANES;  // this group's lanes inside the 64-bit ballot
-    mask = LANES == 64 ? mask : (mask >> sh) & ((1ull << LANES) - 1ull);
+    if constexpr (LANES < 64) mask = (mask >> sh) & ((1ull << LANES) - 1ull);
     if (on) {
         w.cval[a] = 0.0; w.crew[a] = 0.0; w.cvis[a] = 0; w.cidx[a] = -1;
         if (GUMBEL) {
@@ -60,7 +73,7 @@ __device__ __forceinline__ void write_root(const Dev &d, int t, int a, bool on, 
     }
 }
 
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_reset(Dev d, const void *root_prior, const double *root_value,
                                                      const float *root_hidden, const int32_t *root_to_play,
                                                      const uint8_t *legal, const double *gumbel,
@@ -85,17 +98,20 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_reset(Dev d, const void *root_prio
     }
 }
 
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_select(Dev d, const double *noise, int noise_max_calls,
                                                       float *out_parent_hidden, int32_t *out_parent,
                                                       int32_t *out_action)
 {
+    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
+    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
     bool on = a < d.L.A;
     const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
     int action, ntp, depth;
-    int parent = descend<LANES, GUMBEL>(d, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct);
+    int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
     if (a == 0) {
         d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
         if (out_parent) out_parent[t] = parent;
@@ -107,11 +123,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_select(Dev d, const double *noise,
     }
 }
 
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_expand_backup(Dev d, int leaf, const float *logits,
                                                              const double *value, const double *reward,
                                                              const float *next_hidden)
 {
+    __shared__ __align__(16) double s_bk[MZ_BLOCK];
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
     bool on = a < d.L.A;
@@ -121,7 +138,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_expand_backup(Dev d, int leaf, con
         return;
     }
     float lg = on ? logits[(long long)t * d.L.A + a] : 0.0f;
-    expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t]);
+    expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t],
+                                 s_bk + (threadIdx.x / LANES) * LANES);
     if (next_hidden) {
         float *dst = d.hidden + ((long long)t * d.L.N + leaf) * d.L.H;
         for (int i = a; i < d.L.H; i += LANES) dst[i] = next_hidden[(long long)t * d.L.H + i];
@@ -130,27 +148,32 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_expand_backup(Dev d, int leaf, con
 }
 
 // Whole search in one launch with the synthetic hash network as the leaf evaluator.
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int first_leaf, int n_sims,
                                                            const double *noise, int noise_max_calls)
 {
+    __shared__ __align__(16) double s_bk[MZ_BLOCK];
+    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
+    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
     const int A = d.L.A, H = d.L.H;
     bool on = a < A;
     const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
     float *hid = d.hidden + (long long)t * d.L.N * H;
+    double *bk = s_bk + (threadIdx.x / LANES) * LANES;
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct);
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
         int action, ntp, depth;
-        int parent = descend<LANES, GUMBEL>(d, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+        int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
         const float *ph = hid + (long long)parent * H;
         uint32_t pcode = (uint32_t)ph[0] | ((uint32_t)ph[1] << 16);
         uint32_t ccode = hash2(pcode, 300 + action);
         uint32_t src = hn.parent_predicts ? pcode : ccode;
         float lg = on ? hash_logit(src, a, hn.logit_shift) : 0.0f;
         expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, hash_value(src),
-                                     hash_reward(ccode, hn.reward_on));
+                                     hash_reward(ccode, hn.reward_on), bk);
         float *dst = hid + (long long)leaf * H;
         for (int i = a; i < H; i += LANES) dst[i] = hash_hidden(ccode, i);
         __threadfence_block();  // this group's stores are read by its other lanes in the next descent
@@ -169,14 +192,6 @@ struct NetDev {
     int io[12];  // in_hidden, in_action, out_next, out_reward, out_policy, out_value, H, A, action_size, support, norm_groups, obs
 };
 
-template <int LANES>
-__device__ __forceinline__ float gminf(float v)
-{
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) { float o = __shfl_xor(v, m, LANES); v = o < v ? o : v; }
-    return v;
-}
-
 // utils/network_utils.py:75-96 over `n` logits held in LDS: float32 softmax, expectation over the
 // integer support in float64, inverse of h(x) = sign(x)(sqrt(|x|+1)-1) + 0.001x.
 template <int LANES>
@@ -185,15 +200,15 @@ __device__ __forceinline__ double support_to_scalar(const float *lg, int n, int 
     const int L = (n - 1) / 2;
     float mx = -__builtin_huge_valf();
     for (int i = a; i < n; i += LANES) mx = lg[i] > mx ? lg[i] : mx;
-    mx = gmaxf<LANES>(mx);
+    int W = 2;
+    while (W < n && W < LANES) W <<= 1;  // lanes that hold elements
+    mx = gmaxf<LANES>(mx, W);
     float s = 0.0f;
     for (int i = a; i < n; i += LANES) s += expf(lg[i] - mx);
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, LANES);
+    s = gsumf_any<LANES>(s, W);
     double x = 0.0;
     for (int i = a; i < n; i += LANES) x += (double)(expf(lg[i] - mx) / s) * (double)(i - L);
-#pragma unroll
-    for (int m = LANES / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, LANES);
+    x = gsumd_any<LANES>(x, W);
     const double eps = 0.001;
     double sg = x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
     double t = (sqrt(1 + 4 * eps * (fabs(x) + 1 + eps)) - 1) / (2 * eps);
@@ -217,15 +232,24 @@ __device__ __forceinline__ void dense_run(const int32_t *meta, const float *w, f
     for (int l = 0; l < n_levels; l++) {
         const int n_rows = lv[4 * l], kmax = lv[4 * l + 1], row0 = lv[4 * l + 3];
         const float *WT = w + lv[4 * l + 2];
+        const float4 *W4 = reinterpret_cast<const float4 *>(WT);
+        const int k4n = kmax >> 2;
         for (int r = a; r < n_rows; r += LANES) {
-            const int32_t *ds = rows + 4 * (row0 + r);
-            const float *x = sc + ds[0];
+            const int4 ds = *reinterpret_cast<const int4 *>(rows + 4 * (row0 + r));
+            const float4 *x4 = reinterpret_cast<const float4 *>(sc + ds.x);
             float acc = bias[row0 + r];
-            for (int k = 0; k < kmax; k++) acc = fmaf(WT[k * n_rows + r], x[k], acc);
-            if (ds[3] >= 0) acc += sc[ds[3]];
-            if (ds[2] == 1) acc = acc > 0.0f ? acc : 0.0f;
-            else if (ds[2] == 2) acc = acc > 0.0f ? acc : expm1f(acc);
-            sc[ds[1]] = acc;
+#pragma unroll 4
+            for (int k = 0; k < k4n; k++) {
+                float4 wv = W4[k * n_rows + r], xv = x4[k];
+                acc = fmaf(wv.x, xv.x, acc);
+                acc = fmaf(wv.y, xv.y, acc);
+                acc = fmaf(wv.z, xv.z, acc);
+                acc = fmaf(wv.w, xv.w, acc);
+            }
+            if (ds.w >= 0) acc += sc[ds.w];
+            if (ds.z == 1) acc = acc > 0.0f ? acc : 0.0f;
+            else if (ds.z == 2) acc = acc > 0.0f ? acc : expm1f(acc);
+            sc[ds.y] = acc;
         }
         lds_fence();
     }
@@ -240,7 +264,9 @@ __device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, 
         const float *r = raw + g * per;
         float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
         for (int i = a; i < per; i += LANES) { float v = r[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-        mn = gminf<LANES>(mn); mx = gmaxf<LANES>(mx);
+        int W = 2;
+        while (W < per && W < LANES) W <<= 1;
+        mn = gminf<LANES>(mn, W); mx = gmaxf<LANES>(mx, W);
         float den = (mx - mn) + 1e-5f;
         for (int i = a; i < per; i += LANES) {
             float v = (r[i] - mn) / den;
@@ -260,14 +286,14 @@ struct RootNetDev {
     int obs_off, raw_off, hid_off, pol_off, val_off, obs_size, support, ngroups;
 };
 
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_begin_net(Dev d, RootNetDev rn, const float *obs,
                                                          const uint8_t *legal, const int32_t *to_play,
                                                          const double *dirichlet, double frac,
                                                          const double *gumbel, int max_considered,
                                                          float *out_logits, double *out_value)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     float *rw = lds;
     int32_t *rm = reinterpret_cast<int32_t *>(rw + rn.rep_n_data);
     float *pw = reinterpret_cast<float *>(rm + rn.rep_n_meta);
@@ -296,19 +322,19 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_begin_net(Dev d, RootNetDev rn, co
     long long k = (long long)t * A + a;
     bool lgl = on && legal[k] != 0;
     double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
-    double pr = root_prior<LANES, GUMBEL>(lg, on, lgl, di, frac, a, A, true);
+    double pr = root_prior<RL, GUMBEL>(lg, on, lgl, di, frac, a, A, true);
     write_root<LANES, GUMBEL>(d, t, a, on, pr, value, to_play[t], lgl, (GUMBEL && on) ? gumbel[k] : 0.0,
                               max_considered);
     if (out_logits && on) out_logits[k] = lg;
     if (out_value && a == 0) out_value[t] = value;
 }
 
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int first_leaf, int n_sims,
                                                           const double *noise, int noise_max_calls,
                                                           int scratch_floats)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     float *w = lds;                                                  // [n_data]
     int32_t *meta = reinterpret_cast<int32_t *>(lds + net.n_data);   // [n_meta]
     float *scratch0 = lds + net.n_data + net.n_meta;
@@ -316,6 +342,9 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     for (int i = threadIdx.x; i < net.n_meta; i += MZ_BLOCK) meta[i] = net.meta[i];
     float *sc = scratch0 + (size_t)(threadIdx.x / LANES) * scratch_floats;
     for (int i = threadIdx.x % LANES; i < scratch_floats; i += LANES) sc[i] = 0.0f;
+    __shared__ __align__(16) double s_bk[MZ_BLOCK];
+    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
+    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
     __syncthreads();
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
@@ -323,11 +352,13 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     bool on = a < A;
     const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
     float *hid = d.hidden + (long long)t * d.L.N * H;
+    double *bk = s_bk + (threadIdx.x / LANES) * LANES;
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct);
     const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
         int action, ntp, depth;
-        int parent = descend<LANES, GUMBEL>(d, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+        int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
         // inputs: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
         const float *ph = hid + (long long)parent * H;
         for (int i = a; i < H; i += LANES) sc[net.io[0] + i] = ph[i];
@@ -338,13 +369,13 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         double value = support_to_scalar<LANES>(sc + net.io[5], sup, a);
         double reward = support_to_scalar<LANES>(sc + net.io[3], sup, a);
         float lg = on ? sc[net.io[4] + a] : 0.0f;
-        expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value, reward);
+        expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
         __threadfence_block();
     }
 }
 
 // mcts/action_selection.py:52-70 (PUCT) / :121-138 (Gumbel) + mcts/tree.py:60-68.
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, const double *u,
                                                       int32_t *out_action, double *out_probs,
                                                       double *out_root_value, double *out_q)
@@ -359,37 +390,37 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, 
     int action;
     double prob, qout;
     if constexpr (!GUMBEL) {
-        int total = gsumi<LANES>(on ? s.cv : 0);
+        int total = gsumi<RL>(on ? s.cv : 0);
         int den = total > 1 ? total : 1;
         double vp = total > 0 ? (double)s.cv / (double)den : 1.0 / (double)A;
         const double tiny = 2.2250738585072014e-308;
         double lg = log(vp > tiny ? vp : tiny);
-        double mx = gmax<LANES>(on ? lg : -inf);
+        double mx = gmax<RL>(on ? lg : -inf);
         double tt = temperature > 1e-27 ? temperature : 1e-27;
         lg = (lg - mx) / tt;
         double e = on ? exp(lg) : 0.0;
-        double es = gsum_np<LANES, double>(e, a, A);
+        double es = gsum_np<RL, double>(e, a, A);
         prob = e / es;
         // legacy np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
         double acc = 0.0, mine = 0.0;
-        for (int i = 0; i < A; i++) { acc += gshfl<LANES>(prob, i); if (a == i) mine = acc; }
+        for (int i = 0; i < A; i++) { acc += __shfl(prob, i, RL); if (a == i) mine = acc; }
         mine = mine / acc;
         double uu = u ? u[t] : 0.0;
-        int idx = gsumi<LANES>((on && mine <= uu) ? 1 : 0);
+        int idx = gsumi<RL>((on && mine <= uu) ? 1 : 0);
         action = idx < A ? idx : A - 1;
         qout = s.r + d.discount * s.v;
     } else {
         int vsum;
-        double cq = qt_completed_mix<LANES>(d, s, a, on, &vsum);
-        int considered = gmaxi<LANES>(on ? s.cv : -2147483647);
-        double sc = gumbel_score<LANES>(s, on, on ? d.gumbel[(long long)t * A + a] : 0.0, cq, considered);
+        double cq = qt_completed_mix<RL>(d, s, a, on, &vsum);
+        int considered = gmaxi<RL>(on ? s.cv : -2147483647);
+        double sc = gumbel_score<RL>(s, on, on ? d.gumbel[(long long)t * A + a] : 0.0, cq, considered);
         if (!on || !legal) sc = -inf;
-        action = gargmax<LANES>(sc, on ? a : 0x7fffffff);
+        action = gargmax<RL>(sc, on ? a : 0x7fffffff);
         double x = s.prior + cq;
-        double mx = gmax<LANES>(on ? x : -inf);
+        double mx = gmax<RL>(on ? x : -inf);
         x = legal ? x - mx : -1.7976931348623157e308;
         double e = on ? exp(x) : 0.0;
-        double es = gsum_np<LANES, double>(e, a, A);
+        double es = gsum_np<RL, double>(e, a, A);
         prob = e / es;
         qout = cq;
     }
@@ -401,7 +432,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, 
 }
 
 // mcts/mcts.py:22-31 + utils/game_utils.py:71-78 for B roots (root_prior in tree_ops.h).
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const float *logits,
                                                             const double *dirichlet, double frac,
                                                             const uint8_t *legal, int shift_and_mask,
@@ -414,7 +445,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const f
     float lg = on ? logits[k] : 0.0f;
     bool lgl = on && (legal ? legal[k] != 0 : true);
     double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
-    double pr = root_prior<LANES, GUMBEL>(lg, on, lgl, di, frac, a, A, shift_and_mask != 0);
+    double pr = root_prior<RL, GUMBEL>(lg, on, lgl, di, frac, a, A, shift_and_mask != 0);
     if (on) {
         if (GUMBEL) reinterpret_cast<float *>(out)[k] = (float)pr;
         else reinterpret_cast<double *>(out)[k] = pr;
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const f
 }
 
 // One rule at one node, for the module-level functions of the drop-in package.
-template <int LANES, bool GUMBEL>
+template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int depth, int which,
                                                  const double *uniform, double *out_vec, int32_t *out_action)
 {
@@ -432,22 +463,23 @@ __global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int dept
     if (which == 3) {  // selection
         int child;
         double u = (uniform && on) ? uniform[a] : 0.0;
-        int act = select_at<LANES, GUMBEL>(d, t, node, depth, a, on, u, &child);
+        DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, nullptr);
+        int act = select_at<RL, GUMBEL>(d, dc, t, node, depth, a, on, u, &child);
         if (a == 0) *out_action = act;
         return;
     }
     NodeStats s = load_node<GUMBEL>(d, t, node, a, on);
     double r;
     if (which == 0) {
-        r = qt_parent_siblings<LANES>(d, s, on);
+        r = qt_parent_siblings<RL>(d, s, on);
     } else {
         int vsum;
         if constexpr (GUMBEL) {
             if (which == 1) {
-                r = qt_completed_mix<LANES>(d, s, a, on, &vsum);
+                r = qt_completed_mix<RL>(d, s, a, on, &vsum);
             } else {
-                vsum = gsumi<LANES>(on ? s.cv : 0);
-                r = mixed_value<LANES>(d, s, a, on, s.r + d.discount * s.v, vsum);
+                vsum = gsumi<RL>(on ? s.cv : 0);
+                r = mixed_value<RL>(d, s, a, on, s.r + d.discount * s.v, vsum);
             }
         } else {
             r = 0.0;
@@ -500,7 +532,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 struct mz_ctx {
     mz_config cfg;
     Dev d;
-    int lanes;
+    int lanes, rl;    // lanes per tree (group size) and action lanes (smallest power of two >= A, >= 2)
     int n_expanded;   // nodes 1..n_expanded exist (simulations done since reset)
     int selected;     // 1 between mz_select and mz_expand_backup
     int B;            // batch of the last reset
@@ -515,6 +547,7 @@ struct mz_ctx {
 };
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+static bool shape_supported(int lanes, int rl) { return lanes == rl || (lanes == 16 && rl < 16) || (lanes == 64 && rl < 64); }
 
 static void considered_visits_host(int m, int S, int32_t *out)
 {
@@ -566,14 +599,13 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     int lanes = cfg->lanes_per_tree;
     int l0 = next_pow2(A) < 2 ? 2 : next_pow2(A);
     if (lanes == 0) {
-        // Small batches: spread each tree over more lanes so the launch still covers the chip's CUs.
-        long long want = 64ll * 2048 / cfg->max_batch;
-        int w = 1;
-        while (2 * w <= want && 2 * w <= 64) w *= 2;
-        lanes = w > l0 ? w : l0;
+        // Small batches: give each tree a wider group (more lanes for leaf evaluation, more waves in flight).
+        lanes = l0;
+        if (cfg->max_batch <= 1024 && l0 < 64) lanes = 64;
+        else if (cfg->max_batch <= 32768 && l0 < 16) lanes = 16;
     }
-    if (lanes < l0 || lanes > 64 || (lanes & (lanes - 1))) {
-        fail(MZ_ERR_ARG, "mz_create: lanes_per_tree must be a power of two in [n_actions, 64]");
+    if (!shape_supported(lanes, l0)) {
+        fail(MZ_ERR_ARG, "mz_create: lanes_per_tree must be the smallest power of two >= n_actions (min 2), or 16, or 64");
         return nullptr;
     }
     if (hipSetDevice(cfg->device) != hipSuccess) { fail(MZ_ERR_HIP, "mz_create: hipSetDevice failed"); return nullptr; }
@@ -633,6 +665,8 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     }
     d.cv_table = cvt; d.c_table = ct;
     d.players = cfg->players; d.noise_mode = cfg->noise_mode;
+    d.RL = l0;
+    c->rl = l0;
     d.discount = cfg->discount; d.c_visit = cfg->c_visit; d.c_scale = cfg->c_scale;
     d.seed = cfg->seed;
     return c;
@@ -648,26 +682,37 @@ extern "C" void mz_destroy(mz_ctx *c)
     delete c;
 }
 
-// Dispatch a kernel template over (lanes, gumbel).
-#define MZ_DISPATCH(c, KERNEL, grid_groups, stream, ...)                                          \
-    do {                                                                                          \
-        hipStream_t st_ = (hipStream_t)(stream);                                                  \
-        const bool g_ = (c)->cfg.gumbel != 0;                                                     \
-        auto launch_ = [&](auto lanes_tag) {                                                      \
-            constexpr int LN = decltype(lanes_tag)::value;                                        \
-            unsigned grid_ = (unsigned)(((long long)(grid_groups) * LN + MZ_BLOCK - 1) / MZ_BLOCK); \
-            if (g_) hipLaunchKernelGGL((KERNEL<LN, true>), dim3(grid_), dim3(MZ_BLOCK), 0, st_, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<LN, false>), dim3(grid_), dim3(MZ_BLOCK), 0, st_, __VA_ARGS__);   \
-        };                                                                                        \
-        switch ((c)->lanes) {                                                                     \
-        case 2: launch_(std::integral_constant<int, 2>()); break;                                 \
-        case 4: launch_(std::integral_constant<int, 4>()); break;                                 \
-        case 8: launch_(std::integral_constant<int, 8>()); break;                                 \
-        case 16: launch_(std::integral_constant<int, 16>()); break;                               \
-        case 32: launch_(std::integral_constant<int, 32>()); break;                               \
-        default: launch_(std::integral_constant<int, 64>()); break;                               \
-        }                                                                                         \
-    } while (0)
+// Calls f(lanes tag, action-lanes tag, gumbel tag) for the (lanes per tree, action lanes, rule) of a context.
+// Supported shapes: a group is either exactly the action lanes, or 16 or 64 lanes.
+template <int N> using ic = std::integral_constant<int, N>;
+template <typename F>
+static bool dispatch_shape(int lanes, int rl, bool gumbel, F &&f)
+{
+#define MZ_SHAPE(L, R)                                                     \
+    if (lanes == L && rl == R) {                                           \
+        if (gumbel) f(ic<L>(), ic<R>(), std::true_type());                 \
+        else f(ic<L>(), ic<R>(), std::false_type());                       \
+        return true;                                                       \
+    }
+    MZ_SHAPE(2, 2) MZ_SHAPE(16, 2) MZ_SHAPE(64, 2)
+    MZ_SHAPE(4, 4) MZ_SHAPE(16, 4) MZ_SHAPE(64, 4)
+    MZ_SHAPE(8, 8) MZ_SHAPE(16, 8) MZ_SHAPE(64, 8)
+    MZ_SHAPE(16, 16) MZ_SHAPE(64, 16)
+    MZ_SHAPE(32, 32) MZ_SHAPE(64, 32)
+    MZ_SHAPE(64, 64)
+#undef MZ_SHAPE
+    return false;
+}
+
+static unsigned grid_for(long long groups, int lanes) { return (unsigned)((groups * lanes + MZ_BLOCK - 1) / MZ_BLOCK); }
+
+// Heavy kernels run with the context's group size; light once-per-search kernels with group = action lanes.
+#define MZ_LAUNCH(c, KERNEL, light, groups, lds_bytes, stream, ...)                                          \
+    dispatch_shape((light) ? (c)->rl : (c)->lanes, (c)->rl, (c)->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) { \
+        hipLaunchKernelGGL((KERNEL<decltype(L_)::value, decltype(R_)::value, decltype(G_)::value>),           \
+                           dim3(grid_for((groups), decltype(L_)::value)), dim3(MZ_BLOCK), (lds_bytes),        \
+                           (hipStream_t)(stream), __VA_ARGS__);                                               \
+    })
 
 static int check_ctx(mz_ctx *c, const char *fn)
 {
@@ -693,7 +738,7 @@ extern "C" int mz_root_prepare(mz_ctx *c, int32_t B, const float *logits, const 
     if (B < 1 || !logits || !out_prior) return fail(MZ_ERR_ARG, "mz_root_prepare: null/empty argument");
     if (!legal && (shift_and_mask || c->cfg.gumbel)) return fail(MZ_ERR_ARG, "mz_root_prepare: legal mask required");
     if (!c->cfg.gumbel && !dirichlet) return fail(MZ_ERR_ARG, "mz_root_prepare: PUCT needs dirichlet noise");
-    MZ_DISPATCH(c, k_root_prepare, B, stream, (int)B, c->cfg.n_actions, logits, dirichlet, frac, legal,
+    MZ_LAUNCH(c, k_root_prepare, true, B, 0, stream, (int)B, c->cfg.n_actions, logits, dirichlet, frac, legal,
                 (int)shift_and_mask, out_prior);
     return launch_status("mz_root_prepare");
 }
@@ -709,7 +754,7 @@ extern "C" int mz_tree_reset(mz_ctx *c, int32_t B, const void *root_prior, const
     if (c->cfg.gumbel && !gumbel) return fail(MZ_ERR_ARG, "mz_tree_reset: Gumbel search needs gumbel noise");
     c->B = B; c->d.B = B; c->d.tree_id0 = tree_id0;
     c->n_expanded = 0; c->selected = 0;
-    MZ_DISPATCH(c, k_reset, B, stream, c->d, root_prior, root_value, root_hidden, root_to_play, legal, gumbel,
+    MZ_LAUNCH(c, k_reset, true, B, 0, stream, c->d, root_prior, root_value, root_hidden, root_to_play, legal, gumbel,
                 (int)c->cfg.max_considered_actions);
     return launch_status("mz_tree_reset");
 }
@@ -730,7 +775,7 @@ extern "C" int mz_select(mz_ctx *c, const double *noise, int32_t noise_max_calls
     if (c->n_expanded >= c->cfg.n_simulations) return fail(MZ_ERR_STATE, "mz_select: all simulations already done");
     if ((rc = check_noise(c, noise, noise_max_calls, "mz_select"))) return rc;
     if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
-    MZ_DISPATCH(c, k_select, c->B, stream, c->d, noise, (int)noise_max_calls, out_parent_hidden, out_parent,
+    MZ_LAUNCH(c, k_select, false, c->B, 0, stream, c->d, noise, (int)noise_max_calls, out_parent_hidden, out_parent,
                 out_action);
     c->selected = 1;
     return launch_status("mz_select");
@@ -755,7 +800,7 @@ extern "C" int mz_expand_backup(mz_ctx *c, const float *logits, const double *va
     if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup: no pending selection (call mz_select first)");
     if (!logits || !value || !reward) return fail(MZ_ERR_ARG, "mz_expand_backup: null argument");
     int leaf = c->n_expanded + 1;
-    MZ_DISPATCH(c, k_expand_backup, c->B, stream, c->d, leaf, logits, value, reward, next_hidden);
+    MZ_LAUNCH(c, k_expand_backup, false, c->B, 0, stream, c->d, leaf, logits, value, reward, next_hidden);
     c->n_expanded = leaf;
     c->selected = 0;
     return launch_status("mz_expand_backup");
@@ -778,32 +823,15 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         size_t lds = ((size_t)c->net.n_data + c->net.n_meta + (size_t)(MZ_BLOCK / c->lanes) * c->net_scratch) * 4;
         if (lds > 160 * 1024)
             return fail(MZ_ERR_ARG, "mz_search_run: network does not fit in LDS for the fused search; use the step API");
-        hipStream_t st_ = (hipStream_t)stream;
-        const bool g_ = c->cfg.gumbel != 0;
         hipError_t attr_err = hipSuccess;
-        auto launch_ = [&](auto lanes_tag) {
-            constexpr int LN = decltype(lanes_tag)::value;
-            unsigned grid_ = (unsigned)(((long long)c->B * LN + MZ_BLOCK - 1) / MZ_BLOCK);
-            if (g_) {
-                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_net<LN, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((k_search_net<LN, true>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, c->net,
-                                   c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch);
-            } else {
-                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_net<LN, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((k_search_net<LN, false>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, c->net,
-                                   c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch);
-            }
-        };
-        switch (c->lanes) {
-        case 2: launch_(std::integral_constant<int, 2>()); break;
-        case 4: launch_(std::integral_constant<int, 4>()); break;
-        case 8: launch_(std::integral_constant<int, 8>()); break;
-        case 16: launch_(std::integral_constant<int, 16>()); break;
-        case 32: launch_(std::integral_constant<int, 32>()); break;
-        default: launch_(std::integral_constant<int, 64>()); break;
-        }
+        dispatch_shape(c->lanes, c->rl, c->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) {
+            auto kern = k_search_net<decltype(L_)::value, decltype(R_)::value, decltype(G_)::value>;
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid_for(c->B, decltype(L_)::value)), dim3(MZ_BLOCK), lds,
+                               (hipStream_t)stream, c->d, c->net, c->n_expanded + 1, n_sims, noise,
+                               (int)noise_max_calls, c->net_scratch);
+        });
         if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
         c->n_expanded += n_sims;
         return launch_status("mz_search_run");
@@ -812,7 +840,7 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
     if (c->cfg.hidden_size < 2) return fail(MZ_ERR_ARG, "mz_search_run: hash network needs hidden_size >= 2");
     const int32_t *p = reinterpret_cast<const int32_t *>(net_params_h);
     HashNet hn{p[0], p[1], p[2]};
-    MZ_DISPATCH(c, k_search_hash, c->B, stream, c->d, hn, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
+    MZ_LAUNCH(c, k_search_hash, false, c->B, 0, stream, c->d, hn, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
     c->n_expanded += n_sims;
     return launch_status("mz_search_run");
 }
@@ -824,7 +852,7 @@ extern "C" int mz_to_act(mz_ctx *c, double temperature, const double *u, int32_t
     if (rc) return rc;
     if (c->B < 1) return fail(MZ_ERR_STATE, "mz_to_act: no tree");
     if (!out_action || !out_probs || !out_root_value) return fail(MZ_ERR_ARG, "mz_to_act: null output");
-    MZ_DISPATCH(c, k_to_act, c->B, stream, c->d, temperature, u, out_action, out_probs, out_root_value, out_q);
+    MZ_LAUNCH(c, k_to_act, true, c->B, 0, stream, c->d, temperature, u, out_action, out_probs, out_root_value, out_q);
     return launch_status("mz_to_act");
 }
 
@@ -957,20 +985,10 @@ static int node_op(mz_ctx *c, int32_t b, int32_t node, int depth, int which, con
         HIPCHK(hipMemcpyAsync(u_d, uniform_h, (size_t)A * 8, hipMemcpyHostToDevice, st));
     }
     double *vec_d = c->node_tmp;
-    const bool g = c->cfg.gumbel != 0;
-    auto launch = [&](auto tag) {
-        constexpr int LN = decltype(tag)::value;
-        if (g) hipLaunchKernelGGL((k_node_op<LN, true>), dim3(1), dim3(64), 0, st, c->d, (int)b, (int)node, depth, which, u_d, vec_d, c->node_act);
-        else hipLaunchKernelGGL((k_node_op<LN, false>), dim3(1), dim3(64), 0, st, c->d, (int)b, (int)node, depth, which, u_d, vec_d, c->node_act);
-    };
-    switch (c->lanes) {
-    case 2: launch(std::integral_constant<int, 2>()); break;
-    case 4: launch(std::integral_constant<int, 4>()); break;
-    case 8: launch(std::integral_constant<int, 8>()); break;
-    case 16: launch(std::integral_constant<int, 16>()); break;
-    case 32: launch(std::integral_constant<int, 32>()); break;
-    default: launch(std::integral_constant<int, 64>()); break;
-    }
+    dispatch_shape(c->rl, c->rl, c->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) {
+        hipLaunchKernelGGL((k_node_op<decltype(L_)::value, decltype(R_)::value, decltype(G_)::value>), dim3(1), dim3(64),
+                           0, st, c->d, (int)b, (int)node, depth, which, u_d, vec_d, c->node_act);
+    });
     if ((rc = launch_status(fn))) return rc;
     if (out_vec_h) HIPCHK(hipMemcpyAsync(out_vec_h, vec_d, (size_t)A * 8, hipMemcpyDeviceToHost, st));
     if (out_action_h) HIPCHK(hipMemcpyAsync(out_action_h, c->node_act, 4, hipMemcpyDeviceToHost, st));
@@ -1094,32 +1112,15 @@ extern "C" int mz_search_begin_net(mz_ctx *c, int32_t B, const float *obs, const
     if (lds > 160 * 1024) return fail(MZ_ERR_ARG, "mz_search_begin_net: root network does not fit in LDS");
     c->B = B; c->d.B = B; c->d.tree_id0 = tree_id0;
     c->n_expanded = 0; c->selected = 0;
-    hipStream_t st_ = (hipStream_t)stream;
-    const bool g_ = c->cfg.gumbel != 0;
     hipError_t attr_err = hipSuccess;
-    auto launch_ = [&](auto lanes_tag) {
-        constexpr int LN = decltype(lanes_tag)::value;
-        unsigned grid_ = (unsigned)(((long long)B * LN + MZ_BLOCK - 1) / MZ_BLOCK);
-        if (g_) {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_begin_net<LN, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_begin_net<LN, true>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, r, obs, legal,
-                               to_play, dirichlet, frac, gumbel, (int)c->cfg.max_considered_actions, out_logits, out_value);
-        } else {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_begin_net<LN, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_begin_net<LN, false>), dim3(grid_), dim3(MZ_BLOCK), lds, st_, c->d, r, obs, legal,
-                               to_play, dirichlet, frac, gumbel, (int)c->cfg.max_considered_actions, out_logits, out_value);
-        }
-    };
-    switch (c->lanes) {
-    case 2: launch_(std::integral_constant<int, 2>()); break;
-    case 4: launch_(std::integral_constant<int, 4>()); break;
-    case 8: launch_(std::integral_constant<int, 8>()); break;
-    case 16: launch_(std::integral_constant<int, 16>()); break;
-    case 32: launch_(std::integral_constant<int, 32>()); break;
-    default: launch_(std::integral_constant<int, 64>()); break;
-    }
+    dispatch_shape(c->lanes, c->rl, c->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) {
+        auto kern = k_begin_net<decltype(L_)::value, decltype(R_)::value, decltype(G_)::value>;
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid_for(B, decltype(L_)::value)), dim3(MZ_BLOCK), lds, (hipStream_t)stream,
+                           c->d, r, obs, legal, to_play, dirichlet, frac, gumbel,
+                           (int)c->cfg.max_considered_actions, out_logits, out_value);
+    });
     if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_begin_net: could not raise the dynamic LDS limit");
     return launch_status("mz_search_begin_net");
 }

@@ -121,27 +121,49 @@ __device__ __forceinline__ double gumbel_score(const NodeStats &s, bool on, doub
     return sc + (s.cv == considered ? 0.0 : -__builtin_huge_val());
 }
 
+// Per-descent constants hoisted out of the level loop.
+struct DescendCtx {
+    unsigned long long legal;     // root legality mask of the tree
+    unsigned long long key;       // counter-noise key of the tree
+    const double *c_table;        // exploration constants (LDS copy when the kernel staged one)
+    const int32_t *cv_row;        // sequential-halving schedule of this tree's considered count
+    double gumbel_a;              // this lane's Gumbel noise
+};
+
+template <bool GUMBEL>
+__device__ __forceinline__ DescendCtx descend_ctx(const Dev &d, int t, int a, bool on, const double *c_table_lds)
+{
+    DescendCtx c;
+    c.legal = d.legal[t];
+    c.key = GUMBEL ? 0ull : noise_key(d.seed, d.tree_id0 + (unsigned long long)t);
+    c.c_table = c_table_lds ? c_table_lds : d.c_table;
+    c.cv_row = GUMBEL ? d.cv_table + (long long)d.m_considered[t] * d.L.S : nullptr;
+    c.gumbel_a = (GUMBEL && on) ? d.gumbel[(long long)t * d.L.A + a] : 0.0;
+    return c;
+}
+
 // One selection call at `node` (mcts/action_selection.py:11-22 switch; :25-49 PUCT;
 // :73-96 Gumbel root; :99-118 Gumbel interior).  `u` is this lane's tie-break uniform (PUCT).
+// LANES here is the number of action lanes (RL) of the group; only those lanes call it.
 template <int LANES, bool GUMBEL>
-__device__ __forceinline__ int select_at(const Dev &d, int t, int node, int depth, int a, bool on,
-                                         double u, int *child_out)
+__device__ __forceinline__ int select_at(const Dev &d, const DescendCtx &c, int t, int node, int depth, int a,
+                                         bool on, double u, int *child_out)
 {
     const double inf = __builtin_huge_val();
     NodeStats s = load_node<GUMBEL>(d, t, node, a, on);
-    bool legal = depth != 0 || ((d.legal[t] >> a) & 1ull);
+    bool legal = depth != 0 || ((c.legal >> a) & 1ull);
     double score;
     if constexpr (!GUMBEL) {
         double nq = qt_parent_siblings<LANES>(d, s, on);
-        double cc = d.c_table[s.nv];
+        double cc = c.c_table[s.nv];
         double uu = cc * s.prior + sqrt((double)s.nv / (double)(1 + s.cv));
         score = (uu + nq) + 1e-7 * u;
     } else {
         int vsum;
         double cq = qt_completed_mix<LANES>(d, s, a, on, &vsum);
         if (depth == 0) {
-            int considered = d.cv_table[(long long)d.m_considered[t] * d.L.S + vsum];
-            score = gumbel_score<LANES>(s, on, on ? d.gumbel[(long long)t * d.L.A + a] : 0.0, cq, considered);
+            int considered = c.cv_row[vsum < d.L.S ? vsum : d.L.S - 1];
+            score = gumbel_score<LANES>(s, on, c.gumbel_a, cq, considered);
         } else {
             double e = on ? exp(s.prior + cq) : 0.0;
             double es = gsum_np<LANES, double>(e, a, d.L.A);
@@ -150,49 +172,60 @@ __device__ __forceinline__ int select_at(const Dev &d, int t, int node, int dept
     }
     if (!on || !legal) score = -inf;
     int best = gargmax<LANES>(score, on ? a : 0x7fffffff);
-    *child_out = gshfl<LANES>(s.ci, best);
+    // the chosen action's child index sits in lane `best`; min over (lane == best ? ci : big) fetches it
+    *child_out = -gmaxi<LANES>(a == best ? -s.ci : -0x7fffffff);
     return best;
 }
 
 // MCTS.simulate, mcts/mcts.py:98-114.  Returns the parent node; action/next_to_play/depth by reference.
 // Records the path for the backup.  noise: MZ_NOISE_BUFFER rows for this tree, or NULL.
-template <int LANES, bool GUMBEL>
-__device__ __forceinline__ int descend(const Dev &d, int t, int a, bool on, const double *noise,
-                                       int noise_max_calls, int *action_out, int *ntp_out, int *depth_out)
+// The RL action lanes walk the tree; the result is then shared with the rest of the group.
+template <int LANES, int RL, bool GUMBEL>
+__device__ __forceinline__ int descend(const Dev &d, const DescendCtx &c, int t, int a, bool on,
+                                       const double *noise, int noise_max_calls, int *action_out, int *ntp_out,
+                                       int *depth_out)
 {
     int node = 0, depth = 0, ntp = 0, action = 0;
-    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-    const unsigned long long tree = d.tree_id0 + (unsigned long long)t;
-    int32_t *path = d.path + (long long)t * d.L.S;
-    while (true) {
-        double u = 0.0;
-        if constexpr (!GUMBEL) {
-            if (on) {
-                if (d.noise_mode == 0) u = noise_u(d.seed, tree, calls, (unsigned)a);
-                else if (d.noise_mode == 1 && (int)calls < noise_max_calls)
-                    u = noise[(long long)calls * d.L.A + a];
+    if (LANES == RL || a < RL) {
+        uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
+        int32_t *path = d.path + (long long)t * d.L.S;
+        while (true) {
+            double u = 0.0;
+            if constexpr (!GUMBEL) {
+                if (on) {
+                    if (d.noise_mode == 0) u = noise_from_key(c.key, calls, (unsigned)a);
+                    else if (d.noise_mode == 1 && (int)calls < noise_max_calls)
+                        u = noise[(long long)calls * d.L.A + a];
+                }
+                calls++;
             }
-            calls++;
+            int child;
+            action = select_at<RL, GUMBEL>(d, c, t, node, depth, a, on, u, &child);
+            if (a == 0 && depth < d.L.S) path[depth] = (node << 6) | action;
+            ntp = d.players == 1 ? ntp : 1 - ntp;
+            depth++;
+            if (child < 0 || depth > d.L.S) break;  // depth bound: a malformed tree cannot spin forever
+            node = child;
         }
-        int child;
-        action = select_at<LANES, GUMBEL>(d, t, node, depth, a, on, u, &child);
-        if (a == 0 && depth < d.L.S) path[depth] = (node << 6) | action;
-        ntp = d.players == 1 ? ntp : 1 - ntp;
-        depth++;
-        if (child < 0 || depth > d.L.S) break;  // depth bound: a malformed tree cannot spin forever
-        node = child;
+        if constexpr (!GUMBEL) { if (a == 0) d.noise_calls[t] = calls; }
     }
-    if constexpr (!GUMBEL) { if (a == 0) d.noise_calls[t] = calls; }
+    if constexpr (RL < LANES) {  // lanes beyond the action lanes take lane 0's result
+        int packed = (node << 6) | action;
+        packed = gshfl<LANES>(packed, 0);
+        int dn = gshfl<LANES>((depth << 1) | ntp, 0);
+        node = packed >> 6; action = packed & 63; depth = dn >> 1; ntp = dn & 1;
+    }
     *action_out = action; *ntp_out = ntp; *depth_out = depth;
     return node;
 }
 
 // MCTS.expand (mcts/mcts.py:116-141) for leaf index `leaf`, then MCTS.backward (:143-164) along the
 // recorded path.  `logit` is this lane's prior logit; value/reward are group-uniform.
+// `lds_r`: LANES doubles of LDS owned by this group (staging of the per-level rewards).
 template <int LANES, bool GUMBEL>
 __device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool on, int parent, int action,
                                               int ntp, int depth, int leaf, float logit, double value,
-                                              double reward)
+                                              double reward, double *lds_r)
 {
     // --- expansion: a fresh record for the leaf, links in the parent
     RowView lf = view(d, t, leaf);
@@ -210,7 +243,8 @@ __device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool o
         else reinterpret_cast<double *>(lf.prior)[a] = (double)logit;
     }
     // --- backup: lane i of a chunk owns level i above the leaf; loads are independent, only the
-    // discounted return L is a serial recurrence (reward + gamma * L, mcts/mcts.py:162).
+    // discounted return L is a serial recurrence (reward + gamma * L, mcts/mcts.py:162), which every
+    // lane replays from the rewards staged in LDS (reads run ahead of the dependent multiply-add chain).
     const int32_t *path = d.path + (long long)t * d.L.S;
     double L = value, carry = value;
     for (int base = 0; base < depth; base += LANES) {
@@ -228,16 +262,33 @@ __device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool o
             cvs = pw.cvis[pa];
         }
         int cnt = depth - base < LANES ? depth - base : LANES;
+        lds_r[a] = r;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         double myL = 0;
-        for (int j = 0; j < cnt; j++) {
-            double rj = gshfl<LANES>(r, j);
+        int j = 0;
+        for (; j + 4 <= cnt; j += 4) {
+            double r0 = lds_r[j], r1 = lds_r[j + 1], r2 = lds_r[j + 2], r3 = lds_r[j + 3];
+            if (a == j) myL = L;
+            L = r0 + d.discount * L;
+            if (a == j + 1) myL = L;
+            L = r1 + d.discount * L;
+            if (a == j + 2) myL = L;
+            L = r2 + d.discount * L;
+            if (a == j + 3) myL = L;
+            L = r3 + d.discount * L;
+        }
+        for (; j < cnt; j++) {
+            double rj = lds_r[j];
             if (a == j) myL = L;
             L = rj + d.discount * L;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         double newV = (V * (double)nv + (tp == ntp ? myL : -myL)) / (double)(nv + 1);
         double below = __shfl_up(newV, 1, LANES);
         double child_new = a == 0 ? carry : below;
-        carry = gshfl<LANES>(newV, cnt - 1);
+        if (base + LANES < depth) carry = gshfl<LANES>(newV, cnt - 1);
         if (valid) {
             pw.hdr->visits = nv + 1;
             pw.hdr->value = newV;

@@ -3,15 +3,17 @@ checker consume.
 
 A program is scheduled into LEVELS: a step's level is one more than the deepest level among the
 producers of its input and skip tensors, so all rows (output neurons) of a level can be computed
-at once from the activation scratch.  Per level the weights are stored TRANSPOSED and zero-padded
-to the level's widest input, ``W_T[k][row]``, so consecutive lanes read consecutive floats.
+at once from the activation scratch.  Per level the weights are zero-padded to the level's widest
+input (rounded up to 4) and stored as ``W4[k/4][row][4]``: lane `row` reads one 16-byte vector per
+four inputs, consecutive lanes read consecutive vectors.  Tensor offsets in the scratch are multiples
+of 4 floats so the inputs are read as 16-byte vectors too.
 
 int32 meta:
   [0] n_levels   [1] scratch floats per tree   [2] total rows   [3] floats in data   [4] bias offset in data
   [5] index of the level table in meta          [6] index of the row table in meta    [7] reserved
   level table, 4 ints per level: n_rows, kmax, weight offset in data, first row
   row table, 4 ints per row:     input offset, output offset, activation (0 none, 1 relu, 2 elu), skip offset or -1
-float32 data: per level W_T[kmax][n_rows], then the biases of all rows.
+float32 data: per level W4[kmax/4][n_rows][4] (kmax a multiple of 4), then the biases of all rows.
 Offsets of inputs/outputs are positions in a tree's activation scratch.
 """
 from __future__ import annotations
@@ -52,9 +54,10 @@ def pack(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = No
     sizes: Dict[str, int] = {}
     level_of: Dict[str, int] = {}
     off = 0
+    al = lambda x: (int(x) + 3) // 4 * 4  # noqa: E731  (16-byte alignment of every tensor)
     for name, size in inputs.items():
         slots[name], sizes[name], level_of[name] = off, int(size), 0
-        off += int(size)
+        off = al(off + int(size))
     for name, (base, o, size) in aliases.items():
         slots[name], sizes[name], level_of[name] = slots[base] + o, int(size), 0
     levels: List[list] = []
@@ -65,7 +68,7 @@ def pack(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = No
         lv = 1 + max(level_of[s.inp], level_of[s.skip] if s.skip else 0)
         level_of[s.out] = lv
         slots[s.out], sizes[s.out] = off, int(N)
-        off += int(N)
+        off = al(off + int(N))
         while len(levels) < lv:
             levels.append([])
         levels[lv - 1].append(s)
@@ -74,7 +77,7 @@ def pack(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = No
     level_tab, row_tab, blobs, biases = [], [], [], []
     w_off, row0, macs = 0, 0, 0
     for lv in levels:
-        kmax = max(int(s.W.shape[1]) for s in lv)
+        kmax = al(max(int(s.W.shape[1]) for s in lv))
         rows = sum(int(s.W.shape[0]) for s in lv)
         WT = np.zeros((kmax, rows), np.float32)
         r = 0
@@ -90,14 +93,18 @@ def pack(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = No
         # a row that reads fewer than kmax inputs multiplies the zero padding by whatever follows its
         # input in the scratch, so the scratch must extend kmax floats past every input offset
         level_tab += [rows, kmax, w_off, row0]
-        blobs.append(WT.reshape(-1))
+        blobs.append(WT.reshape(kmax // 4, 4, rows).transpose(0, 2, 1).reshape(-1))
         w_off += WT.size
         row0 += rows
     pad = max(level_tab[1::4], default=0)
     meta[1] = off + pad
-    meta[3] = w_off + len(biases)
+    n_data = al(w_off + len(biases))  # padded so that what follows the data in LDS stays 16-byte aligned
+    meta[3] = n_data
     meta[4] = w_off
-    data = np.concatenate(blobs + [np.asarray(biases, np.float32)]) if blobs else np.zeros(0, np.float32)
+    data = np.zeros(n_data, np.float32)
+    if blobs:
+        flat = np.concatenate(blobs + [np.asarray(biases, np.float32)])
+        data[:flat.size] = flat
     return PackedProgram(np.asarray(meta + level_tab + row_tab, np.int32), data.astype(np.float32), slots, sizes, macs)
 
 

@@ -680,7 +680,7 @@ void orc_search_batch_hash(const orc_cfg *c, const orc_hashnet *hn, int H, int64
 
 /* ---------------------------------------------------------------- network leaf evaluation
  * A lowered MuZero network is a "dense program" (muzero_amd/packing.py documents the flat
- * layout): levels of rows, each row = one output neuron  act(bias + sum_k W_T[k][row] * x[in+k]
+ * layout): levels of rows, each row = one output neuron  act(bias + sum_k W4[k/4][row][k%4] * x[in+k]
  * (+ skip)).  For the reference's fully connected network (network.py:405-479,
  * utils/network_utils.py:8-22: Linear + ELU stacks) this is exactly its forward pass; plain
  * float32 multiply-adds in k order.  Compared against the reference's own outputs at 1e-5. */
@@ -695,7 +695,8 @@ void orc_dense_run(const int32_t *meta, const float *data, float *scratch)
         for (int r = 0; r < n_rows; r++) {
             const int32_t *d = rows + 4 * (row0 + r);
             float acc = bias[row0 + r];
-            for (int k = 0; k < kmax; k++) acc += WT[(size_t)k * n_rows + r] * scratch[d[0] + k];
+            for (int k = 0; k < kmax; k++)
+                acc += WT[((size_t)(k / 4) * n_rows + r) * 4 + (k % 4)] * scratch[d[0] + k];
             if (d[3] >= 0) acc += scratch[d[3]];
             if (d[2] == 1) acc = acc > 0 ? acc : 0;
             else if (d[2] == 2) acc = acc > 0 ? acc : expm1f(acc);

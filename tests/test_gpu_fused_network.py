@@ -38,7 +38,7 @@ def test_fused_mlp_search_vs_checker(gumbel):
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     ref = orc.search_batch_net(cfg, packed, logits, hidden, value, legal, tp, dirichlet=di, frac=0.25, gumbel=g,
                                seed=5, tree_id0=0, n_threads=8)
-    for lanes in (2, 8, 64):
+    for lanes in (2, 16, 64):
         eng = SearchEngine(cfg, packed.H, B, seed=5, lanes_per_tree=lanes)
         eng.set_network(packed)
         prior = eng.root_prepare(logits, legal, di, 0.25)

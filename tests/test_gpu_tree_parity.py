@@ -28,7 +28,7 @@ def _lanes_options(A):
     l0 = 2
     while l0 < A:
         l0 *= 2
-    return sorted({l0, min(64, l0 * 2), 64})
+    return sorted({l0, max(l0, 16), 64})
 
 
 @pytest.mark.parametrize('name', ['search_hash_puct.npz', 'search_hash_gumbel.npz'])
