@@ -193,26 +193,67 @@ struct NetDev {
 };
 
 // utils/network_utils.py:75-96 over `n` logits held in LDS: float32 softmax, expectation over the
-// integer support in float64, inverse of h(x) = sign(x)(sqrt(|x|+1)-1) + 0.001x.
-template <int LANES>
-__device__ __forceinline__ double support_to_scalar(const float *lg, int n, int a)
+// integer support in float64, inverse of h(x) = sign(x)(sqrt(|x|+1)-1) + 0.001x.  Two vectors
+// (value and reward logits) go through together so their dependent chains overlap.
+__device__ __forceinline__ double inv_value_transform(double x)
 {
-    const int L = (n - 1) / 2;
-    float mx = -__builtin_huge_valf();
-    for (int i = a; i < n; i += LANES) mx = lg[i] > mx ? lg[i] : mx;
-    int W = 2;
-    while (W < n && W < LANES) W <<= 1;  // lanes that hold elements
-    mx = gmaxf<LANES>(mx, W);
-    float s = 0.0f;
-    for (int i = a; i < n; i += LANES) s += expf(lg[i] - mx);
-    s = gsumf_any<LANES>(s, W);
-    double x = 0.0;
-    for (int i = a; i < n; i += LANES) x += (double)(expf(lg[i] - mx) / s) * (double)(i - L);
-    x = gsumd_any<LANES>(x, W);
     const double eps = 0.001;
     double sg = x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
     double t = (sqrt(1 + 4 * eps * (fabs(x) + 1 + eps)) - 1) / (2 * eps);
     return sg * (t * t - 1);
+}
+
+template <int LANES>
+__device__ __forceinline__ void support_to_scalar2(const float *lgA, const float *lgB, int n, int a,
+                                                   double *outA, double *outB)
+{
+    const int L = (n - 1) / 2;
+    int W = 2;
+    while (W < n && W < LANES) W <<= 1;  // lanes that hold elements
+    const bool single = n <= LANES;      // one element per lane: keep it in registers
+    float mA = -__builtin_huge_valf(), mB = -__builtin_huge_valf();
+    float vA = 0, vB = 0;
+    if (single) {
+        if (a < n) { vA = lgA[a]; vB = lgB[a]; mA = vA; mB = vB; }
+    } else {
+        for (int i = a; i < n; i += LANES) { mA = lgA[i] > mA ? lgA[i] : mA; mB = lgB[i] > mB ? lgB[i] : mB; }
+    }
+    mA = gmaxf<LANES>(mA, W); mB = gmaxf<LANES>(mB, W);
+    float sA = 0.0f, sB = 0.0f, eA = 0.0f, eB = 0.0f;
+    if (single) {
+        if (a < n) { eA = expf(vA - mA); eB = expf(vB - mB); }
+        sA = eA; sB = eB;
+    } else {
+        for (int i = a; i < n; i += LANES) { sA += expf(lgA[i] - mA); sB += expf(lgB[i] - mB); }
+    }
+    sA = gsumf_any<LANES>(sA, W); sB = gsumf_any<LANES>(sB, W);
+    double xA = 0.0, xB = 0.0;
+    if (single) {
+        if (a < n) { xA = (double)(eA / sA) * (double)(a - L); xB = (double)(eB / sB) * (double)(a - L); }
+    } else {
+        for (int i = a; i < n; i += LANES) {
+            xA += (double)(expf(lgA[i] - mA) / sA) * (double)(i - L);
+            xB += (double)(expf(lgB[i] - mB) / sB) * (double)(i - L);
+        }
+    }
+    xA = gsumd_any<LANES>(xA, W); xB = gsumd_any<LANES>(xB, W);
+    if constexpr (LANES >= 2) {
+        // one pass of the (long, float64) inverse transform: lane 0 takes the first vector, lane 1 the second
+        double y = inv_value_transform(a == 1 ? xB : xA);
+        *outA = __shfl(y, 0, LANES);
+        *outB = __shfl(y, 1, LANES);
+    } else {
+        *outA = inv_value_transform(xA);
+        *outB = inv_value_transform(xB);
+    }
+}
+
+template <int LANES>
+__device__ __forceinline__ double support_to_scalar(const float *lg, int n, int a)
+{
+    double x, y;
+    support_to_scalar2<LANES>(lg, lg, n, a, &x, &y);
+    return x;
 }
 
 __device__ __forceinline__ void lds_fence()
@@ -355,23 +396,40 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     double *bk = s_bk + (threadIdx.x / LANES) * LANES;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct);
     const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
+#ifdef MZ_STAMPS
+    long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_t;
+#define MZ_STAMP(acc) { long long n_ = clock64(); acc += n_ - st_t; st_t = n_; }
+    st_t = clock64();
+#else
+#define MZ_STAMP(acc)
+#endif
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
         int action, ntp, depth;
         int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+        MZ_STAMP(st_sel)
         // inputs: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
         const float *ph = hid + (long long)parent * H;
         for (int i = a; i < H; i += LANES) sc[net.io[0] + i] = ph[i];
         for (int i = a; i < asz; i += LANES) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
         lds_fence();
         dense_run<LANES>(meta, w, sc, a);
+        MZ_STAMP(st_net)
         minmax_to<LANES>(sc + net.io[2], H, ngroups, a, hid + (long long)leaf * H, nullptr);
-        double value = support_to_scalar<LANES>(sc + net.io[5], sup, a);
-        double reward = support_to_scalar<LANES>(sc + net.io[3], sup, a);
+        double value, reward;
+        support_to_scalar2<LANES>(sc + net.io[5], sc + net.io[3], sup, a, &value, &reward);
         float lg = on ? sc[net.io[4] + a] : 0.0f;
+        MZ_STAMP(st_epi)
         expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
         __threadfence_block();
+        MZ_STAMP(st_bk)
     }
+#ifdef MZ_STAMPS
+    if (a == 0) {  // diagnostic build only: cycle shares per phase, parked in the path buffer (dead after the search)
+        long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
+        o[0] = st_sel; o[1] = st_net; o[2] = st_epi; o[3] = st_bk;
+    }
+#endif
 }
 
 // mcts/action_selection.py:52-70 (PUCT) / :121-138 (Gumbel) + mcts/tree.py:60-68.
@@ -1124,3 +1182,13 @@ extern "C" int mz_search_begin_net(mz_ctx *c, int32_t B, const float *obs, const
     if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_begin_net: could not raise the dynamic LDS limit");
     return launch_status("mz_search_begin_net");
 }
+
+#ifdef MZ_STAMPS
+// Diagnostic build only: copies the first n_bytes of the path buffer (where k_search_net parks its phase stamps).
+extern "C" int mz_debug_read_path(mz_ctx *c, void *out_h, size_t n_bytes)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_h, c->d.path, n_bytes, hipMemcpyDeviceToHost));
+    return MZ_OK;
+}
+#endif

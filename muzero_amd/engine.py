@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libmuzero_amd.so')
+_LIB_PATH = os.environ.get('MUZERO_AMD_LIB') or os.path.join(_HERE, 'libmuzero_amd.so')
 _lib = None
 
 NOISE_COUNTER, NOISE_BUFFER, NOISE_NONE = 0, 1, 2
