@@ -42,10 +42,19 @@ def search_config(gumbel, A, S, players, gamma):
                            c_base=19625, c_init=1.25, dirichlet_alpha=0.25, exploration_frac=0.25)
 
 
+def tictactoe_net_config():
+    return SimpleNamespace(network='resnet', observation_dim=[3, 3, 3], n_actions=9, n_stacked_observations=1,
+                           blocks=1, channels=16, reduced_channels_reward=8, reduced_channels_policy=8,
+                           reduced_channels_value=8, resnet_fc_reward_layers=[16], resnet_fc_policy_layers=[16],
+                           resnet_fc_value_layers=[16], downsample=False, support_limit=1)
+
+
 WORKLOADS = {
     # name: (description, gumbel, A, S, players, gamma, B per GPU, leaf evaluator)
     'cfg2': ('CartPole 256 envs x 50 sims PUCT, random-init MLP (BASELINE configs[1])', False, 2, 50, 1, 0.997, 256, 'mlp'),
     'cfg4s': ('CartPole 8192 envs x 50 sims PUCT search only, random-init MLP (configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'mlp'),
+    'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), leaves evaluated on the matrix cores between the select and expand kernels (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
+    'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
     'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
 }
@@ -94,6 +103,15 @@ def main():
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
         eng.set_network(packed)
         obs = torch.as_tensor(rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32), device=dev)
+    elif leaf in ('step', 'mfma'):
+        from muzero_amd.packing import pack_network_mfma
+        net = MuZeroNetwork(tictactoe_net_config(), seed=0).to(dev)
+        H = net.H
+        eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
+        eng.set_network_mfma(*pack_network_mfma(net))
+        boards = rng.integers(0, 3, size=(B, 9)) - 1  # random (not necessarily reachable) positions
+        planes = np.stack([(boards == -1), (boards == 1), np.ones_like(boards) * -1], axis=1).astype(np.float32)
+        obs = torch.as_tensor(planes.reshape(B, 27), device=dev)
     else:
         H = 144 if A == 9 else 256
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
@@ -116,6 +134,10 @@ def main():
     def step(i=None):
         if leaf == 'mlp':
             eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
+        elif leaf in ('step', 'mfma'):
+            lg0, hid0, val0 = net.initial_flat(obs)
+            prior = eng.root_prepare(lg0, legal, dirichlet, 0.25)
+            eng.reset(prior, val0, hid0, to_play, legal, gnoise, tree_id0=tree_id0)
         else:
             prior = eng.root_prepare(root_logits, legal, dirichlet, 0.25)
             eng.reset(prior, root_value, root_hidden, to_play, legal, gnoise, tree_id0=tree_id0)
@@ -123,6 +145,15 @@ def main():
             ev[i][0].record()
         if leaf == 'mlp':
             eng.search_net()
+        elif leaf == 'mfma':
+            for _ in range(S):
+                eng.select(want_hidden=False)
+                eng.expand_backup_net()
+        elif leaf == 'step':
+            for _ in range(S):
+                parent, action, phid = eng.select()
+                lg, nh, val, rew = net.recurrent_flat(phid, net.encode_actions(action))
+                eng.expand_backup(lg, val, rew, nh)
         else:
             eng.search_hash(4, 1, 1)
         if i is not None:
@@ -159,7 +190,8 @@ def main():
                                         'lanes_per_tree': eng and int(args.lanes)},
         'node_visits_per_sec': nv_all * args.steps / elapsed,
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
-        'roofline': {'bound': 'hbm', 'kernel': 'k_search_net' if leaf == 'mlp' else 'k_search_hash',
+        'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
+                                'mfma': 'k_select+k_net_step+k_expand_backup'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},
     }

@@ -133,6 +133,20 @@ int mz_to_act(mz_ctx *ctx, double temperature, const double *u, int32_t *out_act
 int mz_set_network(mz_ctx *ctx, const int32_t *meta_h, int32_t n_meta, const float *data_h, int32_t n_data,
                    const int32_t *io_h);
 
+/* Uploads the same kind of network in matrix-core layout (muzero_amd/packing.py, pack_mfma) for the
+ * batched leaf evaluation of mz_expand_backup_net: any lowered network whose 32-tree activation tile
+ * fits in LDS, e.g. MuZeroResidualNetwork (network.py:133-186) on a 3x3 board.  steps_h int32[n_steps*12],
+ * tiles_h int32[n_tiles*2], level_start_h int32[n_levels+1], wfrag_h float[n_w] (v_mfma_f32_16x16x4_f32
+ * operand order), bias_h float[n_b], stride = activation floats per tree, io_h as in mz_set_network. */
+int mz_set_network_mfma(mz_ctx *ctx, const int32_t *steps_h, int32_t n_steps, const int32_t *tiles_h,
+                        int32_t n_tiles, const int32_t *level_start_h, int32_t n_levels, const float *wfrag_h,
+                        int64_t n_w, const float *bias_h, int32_t n_b, int32_t stride, const int32_t *io_h);
+
+/* Replaces network.recurrent_inference (mcts/mcts.py:240-243) + MCTS.expand + MCTS.backward
+ * (mcts/mcts.py:116-164) for the pending selection of every tree: leaves are evaluated on the matrix
+ * cores by the network given to mz_set_network_mfma, then expanded and backed up. */
+int mz_expand_backup_net(mz_ctx *ctx, void *stream);
+
 /* Uploads the representation and prediction programs behind network.initial_inference
  * (network.py:86-103).  io_h int32[8] = {obs offset in the representation scratch, raw hidden offset in it,
  * hidden offset in the prediction scratch, policy logits offset, value logits offset, observation

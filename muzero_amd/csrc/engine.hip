@@ -10,6 +10,7 @@
 
 #include "../../include/muzero_amd.h"
 #include "tree_ops.h"
+#include "net_mfma.h"
 
 using namespace mz;
 
@@ -602,6 +603,10 @@ struct mz_ctx {
     void *net_meta_d, *net_data_d;
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
+    MfmaNet mnet;       // MFMA-layout network (mz_set_network_mfma)
+    void *mnet_bufs[5];
+    float *leaf_logits; // [max_batch][A] outputs of the batched leaf evaluation
+    double *leaf_value, *leaf_reward;
 };
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -674,6 +679,7 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     c->n_expanded = 0; c->selected = 0; c->B = 0;
     memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_meta_d = c->net_data_d = nullptr;
     memset(&c->root, 0, sizeof c->root); memset(c->root_bufs, 0, sizeof c->root_bufs);
+    memset(&c->mnet, 0, sizeof c->mnet); memset(c->mnet_bufs, 0, sizeof c->mnet_bufs);
     Dev &d = c->d;
     memset(&d, 0, sizeof d);
     Layout &L = d.L;
@@ -703,6 +709,9 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     rc |= dev_alloc(c, &d.err, (size_t)1);
     rc |= dev_alloc(c, &c->node_tmp, (size_t)MZ_MAX_ACTIONS);
     rc |= dev_alloc(c, &c->node_act, (size_t)1);
+    rc |= dev_alloc(c, &c->leaf_logits, B * A);
+    rc |= dev_alloc(c, &c->leaf_value, B);
+    rc |= dev_alloc(c, &c->leaf_reward, B);
     int32_t *cvt = nullptr;
     double *ct = nullptr;
     rc |= dev_alloc(c, &cvt, (size_t)(A + 1) * S);
@@ -737,6 +746,7 @@ extern "C" void mz_destroy(mz_ctx *c)
     if (c->net_meta_d) (void)hipFree(c->net_meta_d);
     if (c->net_data_d) (void)hipFree(c->net_data_d);
     for (void *p : c->root_bufs) if (p) (void)hipFree(p);
+    for (void *p : c->mnet_bufs) if (p) (void)hipFree(p);
     delete c;
 }
 
@@ -1192,3 +1202,68 @@ extern "C" int mz_debug_read_path(mz_ctx *c, void *out_h, size_t n_bytes)
     return MZ_OK;
 }
 #endif
+
+extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_steps, const int32_t *tiles_h,
+                                   int32_t n_tiles, const int32_t *level_start_h, int32_t n_levels,
+                                   const float *wfrag_h, int64_t n_w, const float *bias_h, int32_t n_b,
+                                   int32_t stride, const int32_t *io_h)
+{
+    int rc = check_ctx(c, "mz_set_network_mfma");
+    if (rc) return rc;
+    if (!steps_h || !tiles_h || !level_start_h || !wfrag_h || !bias_h || !io_h || n_steps < 1 || n_tiles < 1 || n_levels < 1)
+        return fail(MZ_ERR_ARG, "mz_set_network_mfma: null/empty program");
+    if (io_h[6] != c->cfg.hidden_size || io_h[7] != c->cfg.n_actions)
+        return fail(MZ_ERR_ARG, "mz_set_network_mfma: network hidden size / action count differ from the context's");
+    if (io_h[10] < 1 || io_h[6] % io_h[10]) return fail(MZ_ERR_ARG, "mz_set_network_mfma: hidden size not divisible by normalisation groups");
+    if (stride % 64 != 4) return fail(MZ_ERR_ARG, "mz_set_network_mfma: stride must be 4 mod 64");
+    if ((size_t)stride * MZ_NET_TM * 4 > 160 * 1024) return fail(MZ_ERR_ARG, "mz_set_network_mfma: activations of a 32-tree tile exceed LDS");
+    if (level_start_h[n_levels] != n_tiles) return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent tile table");
+    for (int s = 0; s < n_steps; s++) {
+        const int32_t *st = steps_h + 12 * s;
+        int k16 = st[2], nct = st[9];
+        if (st[3] < 0 || st[3] + k16 * 16 > stride || st[4] < 0 || st[4] + nct * 16 > stride || st[5] + nct * 16 > stride ||
+            st[7] < 0 || (int64_t)st[7] + (int64_t)nct * k16 * 256 > n_w || st[8] < 0 || st[8] + nct * 16 > n_b)
+            return fail(MZ_ERR_ARG, "mz_set_network_mfma: a step addresses outside its buffers");
+    }
+    for (int i = 0; i < n_tiles; i++)
+        if (tiles_h[2 * i] < 0 || tiles_h[2 * i] >= n_steps || tiles_h[2 * i + 1] < 0 ||
+            tiles_h[2 * i + 1] >= steps_h[12 * tiles_h[2 * i] + 9])
+            return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad tile entry");
+    for (void *&p : c->mnet_bufs) if (p) { (void)hipFree(p); p = nullptr; }
+    const void *src[5] = {steps_h, tiles_h, level_start_h, wfrag_h, bias_h};
+    size_t n[5] = {(size_t)n_steps * 12, (size_t)n_tiles * 2, (size_t)n_levels + 1, (size_t)n_w, (size_t)n_b};
+    for (int i = 0; i < 5; i++) {
+        HIPCHK(hipMalloc(&c->mnet_bufs[i], n[i] * 4));
+        HIPCHK(hipMemcpy(c->mnet_bufs[i], src[i], n[i] * 4, hipMemcpyHostToDevice));
+    }
+    MfmaNet &m = c->mnet;
+    m.steps = (const int32_t *)c->mnet_bufs[0]; m.tiles = (const int32_t *)c->mnet_bufs[1];
+    m.level_start = (const int32_t *)c->mnet_bufs[2]; m.wfrag = (const float *)c->mnet_bufs[3];
+    m.bias = (const float *)c->mnet_bufs[4];
+    m.n_steps = n_steps; m.n_levels = n_levels; m.stride = stride;
+    memcpy(m.io, io_h, sizeof m.io);
+    return MZ_OK;
+}
+
+extern "C" int mz_expand_backup_net(mz_ctx *c, void *stream)
+{
+    int rc = check_ctx(c, "mz_expand_backup_net");
+    if (rc) return rc;
+    if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no pending selection (call mz_select first)");
+    if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no network uploaded (call mz_set_network_mfma first)");
+    int leaf = c->n_expanded + 1;
+    size_t lds = (size_t)c->mnet.stride * MZ_NET_TM * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_net_step, dim3((c->B + MZ_NET_TM - 1) / MZ_NET_TM), dim3(MZ_NET_NT), lds, (hipStream_t)stream, c->d,
+                       c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
+    if ((rc = launch_status("mz_expand_backup_net"))) return rc;
+    MZ_LAUNCH(c, k_expand_backup, false, c->B, 0, stream, c->d, leaf, (const float *)c->leaf_logits,
+              (const double *)c->leaf_value, (const double *)c->leaf_reward, (const float *)nullptr);
+    c->n_expanded = leaf;
+    c->selected = 0;
+    return launch_status("mz_expand_backup_net");
+}

@@ -41,7 +41,7 @@ class MzTreeHost(C.Structure):
 
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits',
            'mz_version']
 
@@ -70,6 +70,8 @@ def lib():
         L.mz_search_run.argtypes = [vp, i32, vp, vp, i32, vp]
         L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
+        L.mz_set_network_mfma.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.c_int64, vp, i32, i32, vp]
+        L.mz_expand_backup_net.argtypes = [vp, vp]
         L.mz_search_begin_net.argtypes = [vp, i32, vp, vp, vp, vp, f64, vp, u64, vp, vp, vp]
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
         L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
@@ -275,6 +277,19 @@ class SearchEngine:
             self._action = torch.empty(B, dtype=torch.int32, device=self.device)
             self._phid = torch.empty((B, self.H), dtype=torch.float32, device=self.device) if self.H else None
         return ol, ov
+
+    def set_network_mfma(self, pm, io):
+        """Uploads a network in matrix-core layout (muzero_amd.packing.pack_network_mfma)."""
+        self._mfma_keep = (pm, io)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _check(lib().mz_set_network_mfma(self._ctx, vp(pm.steps), pm.steps.size // 12, vp(pm.tiles), pm.tiles.size // 2,
+                                         vp(pm.level_start), pm.level_start.size - 1, vp(pm.wfrag),
+                                         C.c_int64(pm.wfrag.size), vp(pm.bias), int(pm.bias.size), int(pm.stride),
+                                         vp(io)))
+
+    def expand_backup_net(self):
+        """Leaf evaluation on the matrix cores + expansion + backup for the pending selection."""
+        _check(lib().mz_expand_backup_net(self._ctx, _stream()))
 
     def search_net(self, noise=None):
         """All simulations in one launch, leaves evaluated by the uploaded network."""

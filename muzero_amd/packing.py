@@ -136,3 +136,85 @@ def pack_network(net) -> PackedNetwork:
     rep = pack(net.rep.steps, {'obs': net.obs_size})
     pred = pack(net.pred.steps, {'hidden': H})
     return PackedNetwork(rec, rep, pred, H, net.A, asz, net.obs_size, net.support_limit, net.norm_groups)
+
+
+# ---------------------------------------------------------------------- MFMA layout
+# For programs too large for LDS-resident weights (board ResNets, wide MLPs) a tile of trees keeps
+# its ACTIVATIONS in LDS and streams the weights, pre-swizzled into v_mfma_f32_16x16x4_f32 operand
+# order, from L2.  Per step (one dense layer) and 16-column tile `ct` the weights are stored as
+#   Wfrag[ct][k16][lane 0..63][4]   with   col = ct*16 + (lane & 15),   k = k16*16 + (lane >> 4)*4 + j
+# so one 16-byte load per lane feeds four MFMA k-steps (a wave reads 1 KiB contiguously) and the
+# matching activations of a lane are four consecutive floats (one 16-byte LDS read).
+# int32 step table, 12 ints per step:
+#   level, N, K16 (= ceil(K/16)), in_off, out_off, skip_off (-1), act, w_off (floats), b_off (floats), n_col_tiles, 0, 0
+# int32 tile table: (step, ct) pairs ordered by level; level_start[l] .. level_start[l+1] index it.
+@dataclass
+class PackedMfma:
+    steps: np.ndarray        # int32 [n_steps * 12]
+    tiles: np.ndarray        # int32 [n_tiles * 2]
+    level_start: np.ndarray  # int32 [n_levels + 1]
+    wfrag: np.ndarray        # float32
+    bias: np.ndarray         # float32 (each step padded to 16 columns)
+    stride: int              # activation floats per tree (== 4 mod 64: conflict-free 16-byte operand reads)
+    slots: Dict[str, int]
+    macs: int                # unpadded multiply-accumulates per tree
+    padded_macs: int         # what the MFMA tiles actually compute per tree
+
+
+def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = None) -> PackedMfma:
+    aliases = aliases or {}
+    slots: Dict[str, int] = {}
+    sizes: Dict[str, int] = {}
+    level_of: Dict[str, int] = {}
+    al16 = lambda x: (int(x) + 15) // 16 * 16  # noqa: E731
+    off = 0
+    for name, size in inputs.items():
+        slots[name], sizes[name], level_of[name] = off, int(size), 0
+        off = al16(off + int(size))
+    for name, (base, o, size) in aliases.items():
+        slots[name], sizes[name], level_of[name] = slots[base] + o, int(size), 0
+    table, wblobs, bblobs = [], [], []
+    w_off = b_off = macs = padded = 0
+    per_level: Dict[int, list] = {}
+    for si, s in enumerate(steps):
+        N, K = (int(x) for x in s.W.shape)
+        if sizes[s.inp] != K:
+            raise ValueError(f'step {s.out}: input {s.inp} has {sizes[s.inp]} floats, weight expects {K}')
+        lv = 1 + max(level_of[s.inp], level_of[s.skip] if s.skip else 0)
+        level_of[s.out] = lv
+        slots[s.out], sizes[s.out] = off, N
+        off = al16(off + N)   # 16-float slots: a tile's padded columns never spill into a neighbour
+        k16, nct = (K + 15) // 16, (N + 15) // 16
+        Wp = np.zeros((nct * 16, k16 * 16), np.float32)
+        Wp[:N, :K] = s.W.detach().cpu().numpy()
+        # [ct][col16][k16][kk][j] -> [ct][k16][kk*16 + col16][j]
+        frag = Wp.reshape(nct, 16, k16, 4, 4).transpose(0, 2, 3, 1, 4).reshape(-1)
+        bp = np.zeros(nct * 16, np.float32)
+        bp[:N] = s.b.detach().cpu().numpy()
+        table += [lv - 1, N, k16, slots[s.inp], slots[s.out], slots[s.skip] if s.skip else -1, ACT[s.act], w_off, b_off,
+                  nct, 0, 0]
+        per_level.setdefault(lv - 1, []).extend((si, ct) for ct in range(nct))
+        wblobs.append(frag); bblobs.append(bp)
+        w_off += frag.size; b_off += bp.size
+        macs += N * K; padded += nct * 16 * k16 * 16
+    n_levels = max(per_level) + 1 if per_level else 0
+    tiles, level_start = [], [0]
+    for lv in range(n_levels):
+        for (si, ct) in per_level.get(lv, []):
+            tiles += [si, ct]
+        level_start.append(len(tiles) // 2)
+    stride = off + 16                    # inputs are read up to 15 floats past their end (zero weights)
+    stride += (4 - stride) % 64          # == 4 (mod 64)
+    return PackedMfma(np.asarray(table, np.int32), np.asarray(tiles, np.int32), np.asarray(level_start, np.int32),
+                      np.concatenate(wblobs), np.concatenate(bblobs), int(stride), slots, macs, padded)
+
+
+def pack_network_mfma(net):
+    """Recurrent program (dynamics + prediction of the parent state) of a lowered network in MFMA
+    layout, with the io vector of PackedNetwork.io()."""
+    H, asz = net.H, net.action_size
+    pm = pack_mfma(list(net.dyn.steps) + list(net.pred.steps), {'xa': H + asz}, {'hidden': ('xa', 0, H)})
+    io = np.asarray([pm.slots['xa'], pm.slots['xa'] + H, pm.slots['next_raw'], pm.slots['reward_logits'],
+                     pm.slots['policy_logits'], pm.slots['value_logits'], H, net.A, asz,
+                     2 * net.support_limit + 1, net.norm_groups, net.obs_size], np.int32)
+    return pm, io
