@@ -197,6 +197,37 @@ int mz_node_backward(mz_ctx *ctx, int32_t b, int32_t leaf, int32_t to_play, void
 int mz_tree_import(mz_ctx *ctx, int32_t b, const mz_tree_host *in_h, const double *root_legal_h,
                    const double *gumbel_h, void *stream);
 
+/* Environments stepped on the device for batched self-play. */
+#define MZ_ENV_TICTACTOE 1   /* games/tictactoe.py:9-81 (3x3), games/game.py:56-74 */
+#define MZ_ENV_CARTPOLE 2    /* games/cartpole.py:9-48 = gymnasium CartPole-v1 (public specification) */
+
+/* Caller-owned DEVICE state of B environments (one entry per tree of the context). */
+typedef struct mz_env_state {
+    int32_t kind;               /* MZ_ENV_* */
+    int32_t max_moves;          /* config.max_moves: a game also ends when len(history) > max_moves */
+    int32_t stale_observation;  /* 1 = search move k from the observation saved with move k-1, as
+                                   self_play.py:86-91 + games/game.py:143-149 do; 0 = from the current one */
+    int32_t obs_size;           /* floats per observation: 27 (TicTacToe planes) / 4 (CartPole) */
+    void *state;                /* TicTacToe: int8[B][9] board (-1 X, +1 O, 0 empty); CartPole: f64[B][4] */
+    int32_t *mover;             /* TicTacToe: [B] -1/+1 player about to move; CartPole: NULL */
+    int32_t *to_play;           /* [B] game.to_play() for the next search (in/out) */
+    uint8_t *legal;             /* [B][A] game.legal_actions() for the next search (in/out) */
+    float *cur_obs;             /* [B][obs] current observation (in/out) */
+    float *search_obs;          /* [B][obs] observation the next search starts from (in/out) */
+    int32_t *moves;             /* [B] moves played in the current game (in/out) */
+    const double *reset_state;  /* CartPole: f64[B][4] initial states, uniform(-0.05, 0.05), consumed when an
+                                   environment restarts; TicTacToe: NULL */
+} mz_env_state;
+
+/* Replaces one iteration of SelfPlay.play's loop after the search (self_play.py:99-113) for every
+ * environment: the final action rule (as mz_to_act), game.step(action), the GameHistory.save record of
+ * this move (out_obs_before f32[B][obs] may be NULL, out_action, out_reward f32[B], out_to_play i32[B],
+ * out_probs, out_root_value), termination (out_done u8[B]: terminated or len(history) > max_moves) and
+ * the restart of finished games.  env_h is a HOST struct of device pointers. */
+int mz_act_env_step(mz_ctx *ctx, const mz_env_state *env_h, double temperature, const double *u,
+                    int32_t *out_action, double *out_probs, double *out_root_value, float *out_obs_before,
+                    float *out_reward, uint8_t *out_done, int32_t *out_to_play, void *stream);
+
 /* Sequential-halving schedule, mcts/action_selection.py:160-175 (host, pure integer). out_h i32[S]. */
 int mz_considered_visits(int32_t max_considered_actions, int32_t simulations, int32_t *out_h);
 

@@ -40,8 +40,17 @@ class MzTreeHost(C.Structure):
         'children_values', 'hidden_states')]
 
 
+class MzEnvState(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('max_moves', C.c_int32), ('stale_observation', C.c_int32),
+                ('obs_size', C.c_int32), ('state', C.c_void_p), ('mover', C.c_void_p), ('to_play', C.c_void_p),
+                ('legal', C.c_void_p), ('cur_obs', C.c_void_p), ('search_obs', C.c_void_p), ('moves', C.c_void_p),
+                ('reset_state', C.c_void_p)]
+
+
+ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
+
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits',
            'mz_version']
 
@@ -72,6 +81,7 @@ def lib():
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
         L.mz_set_network_mfma.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.c_int64, vp, i32, i32, vp]
         L.mz_expand_backup_net.argtypes = [vp, vp]
+        L.mz_act_env_step.argtypes = [vp, C.POINTER(MzEnvState), f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mz_search_begin_net.argtypes = [vp, i32, vp, vp, vp, vp, f64, vp, u64, vp, vp, vp]
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
         L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
@@ -311,6 +321,16 @@ class SearchEngine:
         _check(lib().mz_to_act(self._ctx, float(temperature), _ptr(uu), _ptr(action), _ptr(probs), _ptr(value),
                                _ptr(q), _stream()))
         return action, value, probs, q
+
+    def act_env_step(self, env_struct, temperature, u, out):
+        """Final action rule + environment step + trajectory record + restart of finished games.
+        `out`: dict of preallocated device tensors action/probs/value/obs_before/reward/done/to_play."""
+        uu = None if u is None else self._dev(u, torch.float64).reshape(self.B)
+        self._u_keep = uu
+        _check(lib().mz_act_env_step(self._ctx, C.byref(env_struct), float(temperature), _ptr(uu),
+                                     _ptr(out['action']), _ptr(out['probs']), _ptr(out['value']),
+                                     _ptr(out.get('obs_before')), _ptr(out['reward']), _ptr(out['done']),
+                                     _ptr(out['to_play']), _stream()))
 
     def stats(self):
         nv = torch.empty(self.B, dtype=torch.int64, device=self.device)

@@ -91,11 +91,22 @@ def observation_of(code: int, shape=(1, 1, 4)) -> np.ndarray:
     return obs
 
 
-class HashNetwork:
-    """Host-side hash network with the reference's network call interface."""
+def code_of_observation(obs_row: np.ndarray) -> int:
+    """State code of an arbitrary observation: a hash chain over its values rounded to 1/1024."""
+    c = 0x12345678
+    for i, v in enumerate(np.asarray(obs_row, dtype=np.float64).reshape(-1)):
+        c = hash2(c, (int(round(float(v) * 1024)) + 3 * i * 4099) & _M32)
+    return c
 
-    def __init__(self, params: HashNetParams) -> None:
+
+class HashNetwork:
+    """Host-side hash network with the reference's network call interface.  With ``obs_hash`` the
+    root code is a hash of the whole observation (for environments whose observations are real
+    game states); otherwise it is read from the observation's first two cells."""
+
+    def __init__(self, params: HashNetParams, obs_hash: bool = False) -> None:
         self.params = params
+        self.obs_hash = obs_hash
         self.calls = 0
 
     # -- the two methods `MCTS.search` uses ------------------------------
@@ -104,7 +115,7 @@ class HashNetwork:
         obs = observation.detach().cpu().numpy().reshape(observation.shape[0], -1)
         logits, hidden, value = [], [], []
         for row in obs:
-            code = (int(row[0]) | (int(row[1]) << 16)) & _M32
+            code = code_of_observation(row) if self.obs_hash else (int(row[0]) | (int(row[1]) << 16)) & _M32
             logits.append(logits_of(code, self.params))
             hidden.append(hidden_of(code, self.params))
             value.append(value_of(code))

@@ -1,0 +1,184 @@
+"""Batched self-play: B environments stepped on the device, one search per move per environment.
+
+The loop of the reference's `SelfPlay.play` (self_play.py:77-115) for a whole batch of games at once:
+search from each game's observation, act, step the game, record the move, restart finished games.
+Per move this is three launches on the fused path (root inference + root rows, all simulations with
+in-kernel leaf evaluation, action rule + environment step); trees and environments never leave HBM.
+Trajectories are handed back per step in the reference's `GameHistory.save` record layout and can be
+turned into `GameHistory` objects for a replay buffer.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import engine as _engine
+from .games.game import GameHistory
+
+
+class DeviceEnvs:
+    """Caller-owned device state of B environments (mz_env_state of the C ABI)."""
+
+    def __init__(self, kind: str, B: int, device, max_moves: int, stale_observation: bool = True, seed: int = 0):
+        self.kind, self.B, self.device = kind, int(B), device
+        self.rng = np.random.default_rng(seed)
+        if kind == 'tictactoe':
+            self.A, self.obs_size, self.code = 9, 27, _engine.ENV_TICTACTOE
+            self.state = torch.zeros((B, 9), dtype=torch.int8, device=device)
+            self.mover = torch.full((B,), -1, dtype=torch.int32, device=device)
+            obs = torch.zeros((B, 27), dtype=torch.float32, device=device)
+            obs[:, 18:] = -1.0   # empty board, X (-1) to move
+            self.legal = torch.ones((B, 9), dtype=torch.uint8, device=device)
+            self.reset_state = None
+        elif kind == 'cartpole':
+            self.A, self.obs_size, self.code = 2, 4, _engine.ENV_CARTPOLE
+            s0 = self.rng.uniform(-0.05, 0.05, size=(B, 4))
+            self.state = torch.as_tensor(s0, dtype=torch.float64, device=device)
+            self.mover = None
+            obs = self.state.to(torch.float32)
+            self.legal = torch.ones((B, 2), dtype=torch.uint8, device=device)
+            self.reset_state = torch.as_tensor(self.rng.uniform(-0.05, 0.05, size=(B, 4)), device=device)
+        else:
+            raise ValueError(f'unknown environment {kind!r}')
+        self.cur_obs = obs.contiguous()
+        self.search_obs = obs.clone()
+        self.to_play = torch.zeros(B, dtype=torch.int32, device=device)
+        self.moves = torch.zeros(B, dtype=torch.int32, device=device)
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        self.struct = _engine.MzEnvState(self.code, int(max_moves), int(bool(stale_observation)), self.obs_size,
+                                         p(self.state), p(self.mover), p(self.to_play), p(self.legal),
+                                         p(self.cur_obs), p(self.search_obs), p(self.moves), p(self.reset_state))
+
+    def refresh_reset_states(self):
+        """New initial states for environments that restart on the next step (CartPole)."""
+        if self.reset_state is not None:
+            self.reset_state.copy_(torch.as_tensor(self.rng.uniform(-0.05, 0.05, size=(self.B, 4))))
+
+
+class BatchedSelfPlay:
+    """config: the search config plus `max_moves`; network: a muzero_amd.network.MuZeroDenseNetwork
+    (fused in-kernel leaf evaluation when it fits in LDS, matrix-core evaluation otherwise) or any
+    object with the reference's network interface (evaluated between the kernels)."""
+
+    def __init__(self, config, game: str, network, B: int, seed: int = 0, stale_observation: bool = True,
+                 tree_id0: int = 0, device=None, noise_mode=_engine.NOISE_COUNTER):
+        self.config, self.network, self.B = config, network, int(B)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        self.envs = DeviceEnvs(game, B, self.device, config.max_moves, stale_observation, seed)
+        A = self.envs.A
+        self.gumbel = bool(config.gumbel)
+        self.tree_id0 = tree_id0
+        self.rng = np.random.default_rng(seed + 1)
+        self.mode = 'generic'
+        self._noise_mode, self._seed = noise_mode, seed
+        H = None
+        if hasattr(network, 'recurrent_flat'):
+            from .packing import pack_network, pack_network_mfma
+            H = network.H
+            packed = pack_network(network)
+            self.engine = _engine.SearchEngine(config, H, B, seed=seed, noise_mode=noise_mode, device=self.device)
+            lanes_groups = 256 // 16
+            fits = (packed.recurrent.weight_bytes() + lanes_groups * packed.recurrent.scratch * 4 < 150 * 1024 and
+                    packed.represent.weight_bytes() + packed.predict.weight_bytes() < 100 * 1024)
+            if fits:
+                self.engine.set_network(packed)
+                self.mode = 'fused'
+            else:
+                network.to(self.device)
+                self.engine.set_network_mfma(*pack_network_mfma(network))
+                self.mode = 'mfma'
+        else:
+            self.engine = None  # created on the first step, once the hidden size is known
+        self.out = dict(action=torch.empty(B, dtype=torch.int32, device=self.device),
+                        probs=torch.empty((B, A), dtype=torch.float64, device=self.device),
+                        value=torch.empty(B, dtype=torch.float64, device=self.device),
+                        obs_before=torch.empty((B, self.envs.obs_size), dtype=torch.float32, device=self.device),
+                        reward=torch.empty(B, dtype=torch.float32, device=self.device),
+                        done=torch.empty(B, dtype=torch.uint8, device=self.device),
+                        to_play=torch.empty(B, dtype=torch.int32, device=self.device))
+        self.steps_done = 0
+
+    # ------------------------------------------------------------------ one move for every environment
+    def _root_noise(self):
+        A, B = self.envs.A, self.B
+        if self.gumbel:
+            return None, torch.as_tensor(self.rng.gumbel(size=(B, A)), device=self.device)
+        return torch.as_tensor(self.rng.dirichlet([self.config.dirichlet_alpha] * A, size=B), device=self.device), None
+
+    def step(self, temperature: float = 1.0, root_noise=None, u=None, noise=None):
+        """Searches and plays one move in every environment.  root_noise: (dirichlet, gumbel) tensors
+        to use instead of fresh draws; u: the sampling uniforms (PUCT).  Returns the per-step record
+        dict (device tensors, overwritten by the next step)."""
+        e, cfg, eng = self.envs, self.config, self.engine
+        dirichlet, g = root_noise if root_noise is not None else self._root_noise()
+        frac = 0.0 if self.gumbel else cfg.exploration_frac
+        if self.mode == 'fused':
+            eng.begin_net(e.search_obs, e.legal, e.to_play, dirichlet, frac, g, tree_id0=self.tree_id0)
+            eng.search_net(noise)
+        else:
+            net = self.network
+            with torch.no_grad():
+                if self.mode == 'mfma':
+                    lg, hid, val = net.initial_flat(e.search_obs)
+                else:
+                    shape = getattr(net, 'observation_shape', None)
+                    obs = e.search_obs.cpu().reshape(self.B, *shape) if shape else e.search_obs.cpu()
+                    lg, hid, val = net.initial_inference(obs)
+                if eng is None:
+                    H = int(np.prod(hid.shape[1:]))
+                    eng = self.engine = _engine.SearchEngine(cfg, H, self.B, seed=self._seed, device=self.device,
+                                                             noise_mode=self._noise_mode)
+                prior = eng.root_prepare(lg.reshape(self.B, e.A), e.legal, dirichlet, frac)
+                eng.reset(prior, val.reshape(self.B), hid.reshape(self.B, -1), e.to_play, e.legal, g,
+                          tree_id0=self.tree_id0)
+                for _ in range(int(cfg.simulations)):
+                    if self.mode == 'mfma':
+                        eng.select(noise, want_hidden=False)
+                        eng.expand_backup_net()
+                    else:
+                        parent, action, phid = eng.select(noise)
+                        enc = torch.nn.functional.one_hot(action.cpu().long(), net.action_size if hasattr(net, 'action_size') else e.A).float()
+                        l2, nh, v2, r2 = net.recurrent_inference(phid.cpu().reshape(self.B, *hid.shape[1:]), enc)
+                        eng.expand_backup(l2.reshape(self.B, e.A), v2.reshape(self.B), r2.reshape(self.B),
+                                          nh.reshape(self.B, -1))
+        if u is None and not self.gumbel:
+            u = torch.as_tensor(self.rng.random(self.B), device=self.device)
+        e.refresh_reset_states()
+        eng.act_env_step(e.struct, temperature, u, self.out)
+        self.steps_done += 1
+        return self.out
+
+    # ------------------------------------------------------------------ trajectories
+    def play(self, n_steps: int, temperature: float = 1.0, record: bool = True):
+        """Plays n_steps moves in every environment; returns finished games as GameHistory objects
+        (host) when `record` is set."""
+        B, e = self.B, self.envs
+        open_games: List[list] = [[] for _ in range(B)]
+        finished: List[GameHistory] = []
+        for _ in range(n_steps):
+            out = self.step(temperature)
+            if not record:
+                continue
+            rec = {k: v.cpu().numpy().copy() for k, v in out.items()}
+            for b in range(B):
+                open_games[b].append((rec['obs_before'][b], int(rec['action'][b]), float(rec['reward'][b]),
+                                      int(rec['to_play'][b]), rec['probs'][b], float(rec['value'][b])))
+                if rec['done'][b]:
+                    finished.append(self._history(open_games[b]))
+                    open_games[b] = []
+        return finished
+
+    def _history(self, moves) -> GameHistory:
+        e = self.envs
+        if e.kind == 'tictactoe':
+            shape = (3, 3, 3)
+            encoder = lambda a: np.eye(9)[a].reshape(3, 3)  # noqa: E731
+        else:
+            shape = (1, 1, 4)
+            encoder = lambda a: np.eye(2)[a]  # noqa: E731
+        h = GameHistory(encoder, moves[0][0].reshape(shape))
+        for obs, a, r, tp, pi, v in moves:
+            h.save(obs.reshape(shape), a, r, tp, pi, v)
+        return h

@@ -832,3 +832,58 @@ void orc_search_batch_net(const orc_cfg *c, const int32_t *meta, const float *da
         free(t.children_values); free(t.hidden_states); free(scratch); free(nh);
     }
 }
+
+/* ---------------------------------------------------------------- environments
+ * TicTacToe: games/tictactoe.py:14-81 + games/game.py:56-74.  board[9] in {-1 (X), 0, +1 (O)},
+ * *mover = -1/+1 is the player about to move.  Returns terminated; *reward as step() returns it;
+ * obs[27] = planes [board == -1, board == +1, full(next mover)]; legal[9] = board == 0.
+ * `winner` persists inside a game exactly like the attribute: -2 stands for None. */
+int orc_tictactoe_step(double *board, int *mover, int *winner, int action, double *reward, double *obs,
+                       double *legal)
+{
+    board[action] = (double)*mover;      /* no occupancy check (games/tictactoe.py:54) */
+    *mover = -*mover;
+    int terminated = 0;
+    double sums[8];
+    for (int c = 0; c < 3; c++) sums[c] = board[c] + board[3 + c] + board[6 + c];          /* columns */
+    for (int r = 0; r < 3; r++) sums[3 + r] = board[3 * r] + board[3 * r + 1] + board[3 * r + 2]; /* rows */
+    sums[6] = board[0] + board[4] + board[8];
+    sums[7] = board[2] + board[4] + board[6];
+    for (int i = 0; i < 8; i++)
+        if (fabs(sums[i]) == 3) { terminated = 1; *winner = (int)(sums[i] / 3); break; }
+    double filled = 0;
+    for (int i = 0; i < 9; i++) filled += fabs(board[i]);
+    if (filled == 9) { terminated = 1; *winner = 0; }   /* a board-filling win is scored as a tie */
+    *reward = (*winner != -2 && *winner != 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 9; i++) {
+        obs[i] = board[i] == -1 ? 1.0 : 0.0;
+        obs[9 + i] = board[i] == 1 ? 1.0 : 0.0;
+        obs[18 + i] = (double)*mover;
+        legal[i] = board[i] == 0 ? 1.0 : 0.0;
+    }
+    return terminated;
+}
+
+/* CartPole-v1 as the public gymnasium specification states it (games/cartpole.py:9-48 delegates to
+ * gymnasium, which the reference does not pin: this is a SPEC restatement, parity unpinned).
+ * Euler integration, tau 0.02, g 9.8, cart 1.0, pole 0.1, half-length 0.5, force 10; terminated when
+ * |x| > 2.4 or |theta| > 12 degrees; reward 1 per step including the terminating one.  state f64[4]. */
+int orc_cartpole_step(double *s, int action, double *reward, float *obs)
+{
+    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, total_mass = masspole + masscart, length = 0.5;
+    const double polemass_length = masspole * length, force_mag = 10.0, tau = 0.02;
+    const double theta_thr = 12 * 2 * 3.141592653589793 / 360, x_thr = 2.4;
+    double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+    double force = action == 1 ? force_mag : -force_mag;
+    double costheta = cos(theta), sintheta = sin(theta);
+    double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+    double thetaacc = (gravity * sintheta - costheta * temp) /
+                      (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+    double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+    x = x + tau * x_dot; x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot; theta_dot = theta_dot + tau * thetaacc;
+    s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+    for (int i = 0; i < 4; i++) obs[i] = (float)s[i];
+    *reward = 1.0;
+    return x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr;
+}

@@ -380,6 +380,27 @@ def gen_network_fixtures():
 
 # ---------------------------------------------------------------------- misc known answers
 
+def _find_filling_win():
+    """A 9-move game whose last move completes a line (the reference scores it as a tie)."""
+    import itertools
+    lines = [(0, 1, 2), (3, 4, 5), (6, 7, 8), (0, 3, 6), (1, 4, 7), (2, 5, 8), (0, 4, 8), (2, 4, 6)]
+    for perm in itertools.permutations(range(9)):
+        b = [0] * 9
+        ok = True
+        for k, a in enumerate(perm):
+            b[a] = -1 if k % 2 == 0 else 1
+            won = any(abs(b[i] + b[j] + b[l]) == 3 for i, j, l in lines)
+            if won and k < 8:
+                ok = False
+                break
+        if ok and won:
+            return list(perm)
+    raise RuntimeError
+
+
+FILLING_WIN = _find_filling_win()
+
+
 def gen_misc():
     out = {}
     pairs = [(m, S) for m in (0, 1, 2, 3, 4, 5, 7, 8, 9, 16, 18) for S in (1, 5, 10, 25, 50, 100, 200)]
@@ -416,7 +437,10 @@ def gen_misc():
         r = np.random.RandomState(g)
         moves = []
         if g == 0:
-            script = [0, 1, 2, 4, 3, 5, 7, 6, 8]  # X completes 2-... last cell fills the board
+            script = [0, 1, 2, 4, 3, 5, 7, 6, 8]  # a full board without a line
+        elif g == 1:
+            script = [0, 1, 3, 4, 2, 6, 5, 8, 7]  # placeholder, replaced below by a board-filling WIN
+            script = FILLING_WIN
         else:
             script = None
         obs_list, rew_list, term_list, legal_list, tp_list = [], [], [], [], []
@@ -444,8 +468,68 @@ def gen_misc():
     print('misc.npz')
 
 
+def gen_selfplay():
+    """Whole self-play games: the loop of the reference's SelfPlay.play (self_play.py:77-115, which
+    cannot be imported here because it needs ray) spelled out with the reference's own MCTS, TicTacToe
+    and GameHistory objects."""
+    out, gi = {}, 0
+    real_uniform = np.random.uniform
+    for gumbel in (True, False):
+        for seed in (0, 1, 2):
+            cfg = make_config(gumbel, 9, 20, 2, 1, alpha=0.2)
+            cfg.n_stacked_observations, cfg.stack_action, cfg.max_moves = 1, False, 9
+            net = hashnet.HashNetwork(hashnet.HashNetParams(9, 8, 3, 1, 1), obs_hash=True)
+            game = TicTacToe()
+            mcts = MCTS(cfg)
+            np.random.seed(seed)
+            temperature = 1.0
+            observation = game.reset()
+            history = GameHistory(game.action_encoder, observation)
+            cu = CounterUniform(seed, gi)
+            np.random.uniform = cu
+            search_obs = []
+            try:
+                while True:
+                    to_play = game.to_play()
+                    stacked = history.stack_n_observations(-1, cfg.n_stacked_observations, cfg.n_actions, cfg.stack_action)
+                    search_obs.append(np.array(stacked, dtype=np.float64))
+                    action, root_value, probs = mcts.search(net, stacked, game.legal_actions(), game.action_encoder,
+                                                            to_play, temperature)
+                    next_observation, reward, terminated = game.step(action)
+                    history.save(observation, action, reward, to_play, probs, root_value)
+                    observation = next_observation
+                    if terminated or len(history) > cfg.max_moves:
+                        break
+            finally:
+                np.random.uniform = real_uniform
+            p = f'g{gi}_'
+            out[p + 'meta'] = np.array([gumbel, seed, gi, len(history)], dtype=np.int64)
+            out[p + 'observations'] = np.array(history.observations, dtype=np.float64)
+            out[p + 'search_obs'] = np.array(search_obs)
+            out[p + 'actions'] = np.array(history.actions, dtype=np.int64)
+            out[p + 'rewards'] = np.array(history.rewards, dtype=np.float64)
+            out[p + 'to_plays'] = np.array(history.to_plays, dtype=np.int64)
+            out[p + 'probs'] = np.array(history.action_probabilities, dtype=np.float64)
+            out[p + 'root_values'] = np.array(history.root_values, dtype=np.float64)
+            out[p + 'final_obs'] = np.array(observation, dtype=np.float64)
+            # targets the replay buffer would build from this game (games/game.py:185-253)
+            vt, rt, pt = history.make_target(0, 5, cfg.gamma, 5, 9)
+            out[p + 'target_value'], out[p + 'target_reward'] = np.array(vt, dtype=np.float64), np.array(rt, dtype=np.float64)
+            out[p + 'target_policy'] = np.array(pt, dtype=np.float64)
+            out[p + 'return_p0'] = np.float64(history.compute_return(cfg.gamma, 0, 2))
+            out[p + 'return_p1'] = np.float64(history.compute_return(cfg.gamma, 1, 2))
+            gi += 1
+    out['n_games'] = np.int64(gi)
+    np.savez_compressed(os.path.join(HERE, 'selfplay_tictactoe.npz'), **out)
+    print('selfplay_tictactoe.npz', gi, 'games')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
+    if len(sys.argv) > 1 and sys.argv[1] == 'selfplay':
+        gen_selfplay()
+        sys.exit(0)
+    gen_selfplay()
     gen_misc()
     gen_hash_fixtures()
     gen_stream_fixtures()
