@@ -53,6 +53,7 @@ WORKLOADS = {
     # name: (description, gumbel, A, S, players, gamma, B per GPU, leaf evaluator)
     'cfg2': ('CartPole 256 envs x 50 sims PUCT, random-init MLP (BASELINE configs[1])', False, 2, 50, 1, 0.997, 256, 'mlp'),
     'cfg4s': ('CartPole 8192 envs x 50 sims PUCT search only, random-init MLP (configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'mlp'),
+    'cfg4': ('CartPole self-play 8192 envs/GPU x 50 sims PUCT, fused env step, per-step gather of root stats to rank 0 (BASELINE configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'selfplay'),
     'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), leaves evaluated on the matrix cores between the select and expand kernels (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
@@ -95,7 +96,16 @@ def main():
     rng = np.random.default_rng(1 + rank)
     tree_id0 = rank * B
     packed = None
-    if leaf == 'mlp':
+    sp = None
+    if leaf == 'selfplay':
+        from muzero_amd.self_play import BatchedSelfPlay
+        cfg.max_moves = 500
+        net = MuZeroNetwork(cartpole_net_config(), seed=0)
+        packed = pack_network(net)
+        H = packed.H
+        sp = BatchedSelfPlay(cfg, 'cartpole', net, B, seed=rank, tree_id0=tree_id0, device=dev)
+        eng = sp.engine
+    elif leaf == 'mlp':
         torch.manual_seed(0)
         net = MuZeroNetwork(cartpole_net_config(), seed=0)
         packed = pack_network(net)
@@ -132,6 +142,15 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
+        if leaf == 'selfplay':
+            if i is not None:
+                ev[i][0].record()
+            out = sp.step(temperature)
+            if i is not None:
+                ev[i][1].record()
+            if world > 1:  # trajectories of this move to the replay rank
+                mzdist.gather_root_stats(out['action'], out['value'], out['probs'])
+            return out
         if leaf == 'mlp':
             eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
         elif leaf in ('step', 'mfma'):
@@ -190,8 +209,10 @@ def main():
                                         'lanes_per_tree': eng and int(args.lanes)},
         'node_visits_per_sec': nv_all * args.steps / elapsed,
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
+        'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': 'k_select+k_net_step+k_expand_backup'}[leaf],
+                                'mfma': 'k_select+k_net_step+k_expand_backup',
+                                'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': None, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},
     }
@@ -217,7 +238,7 @@ def cpu_baseline(cfg, packed, leaf, A, S, H, B, gumbel, budget_s=8.0):
     legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     g = rng.gumbel(size=(B, A)) if gumbel else None
-    if leaf == 'mlp':
+    if leaf in ('mlp', 'selfplay'):
         net = MuZeroNetwork(cartpole_net_config(), seed=0)
         obs = rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32)
         lg, hid, val = net.initial_inference(torch.as_tensor(obs))

@@ -52,9 +52,12 @@ class DeviceEnvs:
                                          p(self.cur_obs), p(self.search_obs), p(self.moves), p(self.reset_state))
 
     def refresh_reset_states(self):
-        """New initial states for environments that restart on the next step (CartPole)."""
+        """New initial states for environments that restart on the next step (CartPole), drawn on the device."""
         if self.reset_state is not None:
-            self.reset_state.copy_(torch.as_tensor(self.rng.uniform(-0.05, 0.05, size=(self.B, 4))))
+            if getattr(self, '_gen', None) is None:
+                self._gen = torch.Generator(device=self.device)
+                self._gen.manual_seed(int(self.rng.integers(0, 2**31)))
+            self.reset_state.uniform_(-0.05, 0.05, generator=self._gen)
 
 
 class BatchedSelfPlay:
@@ -102,10 +105,17 @@ class BatchedSelfPlay:
 
     # ------------------------------------------------------------------ one move for every environment
     def _root_noise(self):
+        """Fresh Gumbel / Dirichlet root noise for every environment, drawn on the device."""
         A, B = self.envs.A, self.B
+        if getattr(self, '_gen', None) is None:
+            self._gen = torch.Generator(device=self.device)
+            self._gen.manual_seed(int(self.rng.integers(0, 2**31)))
         if self.gumbel:
-            return None, torch.as_tensor(self.rng.gumbel(size=(B, A)), device=self.device)
-        return torch.as_tensor(self.rng.dirichlet([self.config.dirichlet_alpha] * A, size=B), device=self.device), None
+            uu = torch.rand((B, A), dtype=torch.float64, device=self.device, generator=self._gen).clamp_min_(1e-300)
+            return None, -torch.log(-torch.log(uu))
+        alpha = torch.full((B, A), float(self.config.dirichlet_alpha), dtype=torch.float64, device=self.device)
+        gam = torch._standard_gamma(alpha, generator=self._gen).clamp_min_(1e-300)
+        return gam / gam.sum(dim=1, keepdim=True), None
 
     def step(self, temperature: float = 1.0, root_noise=None, u=None, noise=None):
         """Searches and plays one move in every environment.  root_noise: (dirichlet, gumbel) tensors
@@ -144,7 +154,7 @@ class BatchedSelfPlay:
                         eng.expand_backup(l2.reshape(self.B, e.A), v2.reshape(self.B), r2.reshape(self.B),
                                           nh.reshape(self.B, -1))
         if u is None and not self.gumbel:
-            u = torch.as_tensor(self.rng.random(self.B), device=self.device)
+            u = torch.rand(self.B, dtype=torch.float64, device=self.device, generator=self._gen)
         e.refresh_reset_states()
         eng.act_env_step(e.struct, temperature, u, self.out)
         self.steps_done += 1
