@@ -200,6 +200,12 @@ def main():
     sims = world * B * S * args.steps
     nv_all = mzdist.sum_over_ranks(node_visits, dev if world > 1 else 'cpu')
 
+    traffic = None
+    try:  # HBM bytes per launch from the PMC counters, measured offline with rocprofv3 (profiles/hbm_traffic.json)
+        with open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')) as f:
+            traffic = json.load(f).get(args.workload, {}).get('traffic_bytes_per_launch')
+    except OSError:
+        pass
     out = {
         'metric': 'MCTS simulations/sec', 'value': sims / elapsed, 'unit': 'simulations/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -214,7 +220,7 @@ def main():
                                 'mfma': 'k_select+k_net_step+k_expand_backup',
                                 'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': None, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},
+                     'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
