@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mz {
 
@@ -42,6 +43,7 @@ struct Dev {
     int32_t *path;          // [B][S] (node << 6 | action) per level of the last descent
     const int32_t *cv_table;  // [(A + 1)][S] sequential-halving schedules per considered count
     const double *c_table;    // [S + 2]
+    const double *sqrt_table; // [(S + 2)][S + 1] sqrt(n / (1 + c)) for small S (PUCT), else NULL
     int32_t *err;           // device error flag
     int B, players, noise_mode;
     int RL;                 // lanes of a group that hold actions: smallest power of two >= A (>= 2)
@@ -173,6 +175,58 @@ __device__ __forceinline__ int gargmax(double v, int idx, int W = LANES)
     if constexpr (LANES > 32) { if (W > 32) MZ_ARGMAX_STEP(5) }
 #undef MZ_ARGMAX_STEP
     return idx;
+}
+
+// Whole-wavefront reductions (a group that spans the wave): DPP only, result read back through a scalar
+// register, so every lane gets it without touching LDS.  `ident` is the operation's identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_masked(float ident, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident),
+                                                                 __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <typename F>
+__device__ __forceinline__ float wave_reduce(float v, float ident, F f)
+{
+    v = f(v, dpp_mov<MZ_DPP_XOR1>(v));
+    v = f(v, dpp_mov<MZ_DPP_XOR2>(v));
+    v = f(v, dpp_mov<MZ_DPP_HALF_MIRROR>(v));
+    v = f(v, dpp_mov<MZ_DPP_MIRROR>(v));                 // every lane: its row's result
+    v = f(v, dpp_masked<0x142, 0xA>(ident, v));          // row_bcast:15 into rows 1 and 3
+    v = f(v, dpp_masked<0x143, 0xC>(ident, v));          // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <typename F>
+__device__ __forceinline__ double wave_reduce(double v, double ident, F f)
+{
+    auto mv = [](double ident_, double x, auto tag) {
+        constexpr int which = decltype(tag)::value;
+        long long b = __builtin_bit_cast(long long, x), ib = __builtin_bit_cast(long long, ident_);
+        int lo, hi;
+        if constexpr (which == 0) {
+            lo = __builtin_amdgcn_update_dpp((int)ib, (int)b, 0x142, 0xA, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp((int)(ib >> 32), (int)(b >> 32), 0x142, 0xA, 0xF, false);
+        } else {
+            lo = __builtin_amdgcn_update_dpp((int)ib, (int)b, 0x143, 0xC, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp((int)(ib >> 32), (int)(b >> 32), 0x143, 0xC, 0xF, false);
+        }
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    };
+    v = f(v, dpp_mov<MZ_DPP_XOR1>(v));
+    v = f(v, dpp_mov<MZ_DPP_XOR2>(v));
+    v = f(v, dpp_mov<MZ_DPP_HALF_MIRROR>(v));
+    v = f(v, dpp_mov<MZ_DPP_MIRROR>(v));
+    v = f(v, mv(ident, v, std::integral_constant<int, 0>()));
+    v = f(v, mv(ident, v, std::integral_constant<int, 1>()));
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_lane(double v, int lane)  // lane: compile-time-constant lane index
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
 // Lane 0's value to lanes 0..W-1 of the group (W <= 16, group aligned inside a row).

@@ -31,6 +31,19 @@ __device__ __forceinline__ const double *stage_c_table(const Dev &d, double *lds
     return lds_ct;
 }
 
+#define MZ_SQ_LDS (53 * 52)  // sqrt-table entries staged in LDS (covers n_simulations <= 51)
+
+template <bool GUMBEL>
+__device__ __forceinline__ const double *stage_sqrt_table(const Dev &d, double *lds_sq)
+{
+    if constexpr (GUMBEL) return nullptr;
+    const int n = (d.L.S + 2) * (d.L.S + 1);
+    if (!d.sqrt_table || n > MZ_SQ_LDS) return nullptr;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds_sq[i] = d.sqrt_table[i];
+    __syncthreads();
+    return lds_sq;
+}
+
 template <int LANES>
 __device__ __forceinline__ bool group_ids(const Dev &d, int *t, int *a)
 {
@@ -106,12 +119,14 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_select(Dev d, const double *noise,
 {
     __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
     const double *ct = stage_c_table<GUMBEL>(d, s_ct);
+    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
+    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
     bool on = a < d.L.A;
     const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
     int action, ntp, depth;
-    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct);
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
     int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
     if (a == 0) {
         d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
@@ -156,6 +171,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int
     __shared__ __align__(16) double s_bk[MZ_BLOCK];
     __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
     const double *ct = stage_c_table<GUMBEL>(d, s_ct);
+    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
+    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
     const int A = d.L.A, H = d.L.H;
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int
     const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
     float *hid = d.hidden + (long long)t * d.L.N * H;
     double *bk = s_bk + (threadIdx.x / LANES) * LANES;
-    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct);
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
         int action, ntp, depth;
@@ -219,7 +236,11 @@ __device__ __forceinline__ void support_to_scalar2(const float *lgA, const float
     } else {
         for (int i = a; i < n; i += LANES) { mA = lgA[i] > mA ? lgA[i] : mA; mB = lgB[i] > mB ? lgB[i] : mB; }
     }
-    mA = gmaxf<LANES>(mA, W); mB = gmaxf<LANES>(mB, W);
+    auto fmaxl = [](float x, float y) { return y > x ? y : x; };
+    auto faddl = [](float x, float y) { return x + y; };
+    auto daddl = [](double x, double y) { return x + y; };
+    if constexpr (LANES == 64) { mA = wave_reduce(mA, -__builtin_huge_valf(), fmaxl); mB = wave_reduce(mB, -__builtin_huge_valf(), fmaxl); }
+    else { mA = gmaxf<LANES>(mA, W); mB = gmaxf<LANES>(mB, W); }
     float sA = 0.0f, sB = 0.0f, eA = 0.0f, eB = 0.0f;
     if (single) {
         if (a < n) { eA = expf(vA - mA); eB = expf(vB - mB); }
@@ -227,7 +248,8 @@ __device__ __forceinline__ void support_to_scalar2(const float *lgA, const float
     } else {
         for (int i = a; i < n; i += LANES) { sA += expf(lgA[i] - mA); sB += expf(lgB[i] - mB); }
     }
-    sA = gsumf_any<LANES>(sA, W); sB = gsumf_any<LANES>(sB, W);
+    if constexpr (LANES == 64) { sA = wave_reduce(sA, 0.0f, faddl); sB = wave_reduce(sB, 0.0f, faddl); }
+    else { sA = gsumf_any<LANES>(sA, W); sB = gsumf_any<LANES>(sB, W); }
     double xA = 0.0, xB = 0.0;
     if (single) {
         if (a < n) { xA = (double)(eA / sA) * (double)(a - L); xB = (double)(eB / sB) * (double)(a - L); }
@@ -237,8 +259,13 @@ __device__ __forceinline__ void support_to_scalar2(const float *lgA, const float
             xB += (double)(expf(lgB[i] - mB) / sB) * (double)(i - L);
         }
     }
-    xA = gsumd_any<LANES>(xA, W); xB = gsumd_any<LANES>(xB, W);
-    if constexpr (LANES >= 2) {
+    if constexpr (LANES == 64) { xA = wave_reduce(xA, 0.0, daddl); xB = wave_reduce(xB, 0.0, daddl); }
+    else { xA = gsumd_any<LANES>(xA, W); xB = gsumd_any<LANES>(xB, W); }
+    if constexpr (LANES == 64) {
+        double y = inv_value_transform(a == 1 ? xB : xA);
+        *outA = wave_lane(y, 0);
+        *outB = wave_lane(y, 1);
+    } else if constexpr (LANES >= 2) {
         // one pass of the (long, float64) inverse transform: lane 0 takes the first vector, lane 1 the second
         double y = inv_value_transform(a == 1 ? xB : xA);
         *outA = __shfl(y, 0, LANES);
@@ -308,7 +335,12 @@ __device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, 
         for (int i = a; i < per; i += LANES) { float v = r[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
         int W = 2;
         while (W < per && W < LANES) W <<= 1;
-        mn = gminf<LANES>(mn, W); mx = gmaxf<LANES>(mx, W);
+        if constexpr (LANES == 64) {
+            mn = wave_reduce(mn, __builtin_huge_valf(), [](float x, float y) { return y < x ? y : x; });
+            mx = wave_reduce(mx, -__builtin_huge_valf(), [](float x, float y) { return y > x ? y : x; });
+        } else {
+            mn = gminf<LANES>(mn, W); mx = gmaxf<LANES>(mx, W);
+        }
         float den = (mx - mn) + 1e-5f;
         for (int i = a; i < per; i += LANES) {
             float v = (r[i] - mn) / den;
@@ -387,6 +419,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     __shared__ __align__(16) double s_bk[MZ_BLOCK];
     __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
     const double *ct = stage_c_table<GUMBEL>(d, s_ct);
+    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
+    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
     __syncthreads();
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
@@ -395,10 +429,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
     float *hid = d.hidden + (long long)t * d.L.N * H;
     double *bk = s_bk + (threadIdx.x / LANES) * LANES;
-    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct);
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
     const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
 #ifdef MZ_STAMPS
-    long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_t;
+    long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_in = 0, st_mm = 0, st_t;
 #define MZ_STAMP(acc) { long long n_ = clock64(); acc += n_ - st_t; st_t = n_; }
     st_t = clock64();
 #else
@@ -414,9 +448,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         for (int i = a; i < H; i += LANES) sc[net.io[0] + i] = ph[i];
         for (int i = a; i < asz; i += LANES) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
         lds_fence();
+        MZ_STAMP(st_in)
         dense_run<LANES>(meta, w, sc, a);
         MZ_STAMP(st_net)
         minmax_to<LANES>(sc + net.io[2], H, ngroups, a, hid + (long long)leaf * H, nullptr);
+        MZ_STAMP(st_mm)
         double value, reward;
         support_to_scalar2<LANES>(sc + net.io[5], sc + net.io[3], sup, a, &value, &reward);
         float lg = on ? sc[net.io[4] + a] : 0.0f;
@@ -428,7 +464,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
 #ifdef MZ_STAMPS
     if (a == 0) {  // diagnostic build only: cycle shares per phase, parked in the path buffer (dead after the search)
         long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
-        o[0] = st_sel; o[1] = st_net; o[2] = st_epi; o[3] = st_bk;
+        o[0] = st_sel; o[1] = st_net; o[2] = st_epi; o[3] = st_bk; o[4] = st_in; o[5] = st_mm;
     }
 #endif
 }
@@ -863,6 +899,19 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
         return nullptr;
     }
     d.cv_table = cvt; d.c_table = ct;
+    if (!cfg->gumbel && (S + 2) * (S + 1) <= MZ_SQ_LDS) {
+        std::vector<double> sq((size_t)(S + 2) * (S + 1));
+        for (int n = 0; n < S + 2; n++)
+            for (int v = 0; v < S + 1; v++) sq[(size_t)n * (S + 1) + v] = std::sqrt((double)n / (double)(1 + v));
+        double *sqd = nullptr;
+        if (dev_alloc(c, &sqd, sq.size()) != MZ_OK ||
+            hipMemcpy(sqd, sq.data(), sq.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            fail(MZ_ERR_HIP, "mz_create: sqrt table upload failed");
+            mz_destroy(c);
+            return nullptr;
+        }
+        d.sqrt_table = sqd;
+    }
     d.players = cfg->players; d.noise_mode = cfg->noise_mode;
     d.RL = l0;
     c->rl = l0;

@@ -126,14 +126,17 @@ struct DescendCtx {
     unsigned long long legal;     // root legality mask of the tree
     unsigned long long key;       // counter-noise key of the tree
     const double *c_table;        // exploration constants (LDS copy when the kernel staged one)
+    const double *sq_table;       // sqrt(n / (1 + c)) table in LDS, or NULL
     const int32_t *cv_row;        // sequential-halving schedule of this tree's considered count
     double gumbel_a;              // this lane's Gumbel noise
 };
 
 template <bool GUMBEL>
-__device__ __forceinline__ DescendCtx descend_ctx(const Dev &d, int t, int a, bool on, const double *c_table_lds)
+__device__ __forceinline__ DescendCtx descend_ctx(const Dev &d, int t, int a, bool on, const double *c_table_lds,
+                                                  const double *sq_table_lds = nullptr)
 {
     DescendCtx c;
+    c.sq_table = sq_table_lds;
     c.legal = d.legal[t];
     c.key = GUMBEL ? 0ull : noise_key(d.seed, d.tree_id0 + (unsigned long long)t);
     c.c_table = c_table_lds ? c_table_lds : d.c_table;
@@ -156,7 +159,9 @@ __device__ __forceinline__ int select_at(const Dev &d, const DescendCtx &c, int 
     if constexpr (!GUMBEL) {
         double nq = qt_parent_siblings<LANES>(d, s, on);
         double cc = c.c_table[s.nv];
-        double uu = cc * s.prior + sqrt((double)s.nv / (double)(1 + s.cv));
+        // sqrt(N / (1 + n_a)): integer arguments, so a table of the correctly rounded values is bit-identical
+        double sq = c.sq_table ? c.sq_table[s.nv * (d.L.S + 1) + s.cv] : sqrt((double)s.nv / (double)(1 + s.cv));
+        double uu = cc * s.prior + sq;
         score = (uu + nq) + 1e-7 * u;
     } else {
         int vsum;

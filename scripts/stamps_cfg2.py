@@ -22,8 +22,8 @@ for B, lanes in ((256, 64), (8192, 16)):
         eng.search_net()
     buf = np.zeros((B, 50), np.int32)
     lib().mz_debug_read_path(C.c_void_p(eng._ctx), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes))
-    st = buf.view(np.int64).reshape(B, 25)[:, :4].astype(np.float64)
+    st = buf.view(np.int64).reshape(B, 25)[:, :6].astype(np.float64)
     tot = st.sum(1).mean()
     print(f'B={B} lanes={lanes}: cycles/search {tot:.0f}  select {st[:,0].mean()/tot:.2%}  dense {st[:,1].mean()/tot:.2%} '
-          f'epilogue {st[:,2].mean()/tot:.2%}  expand+backup {st[:,3].mean()/tot:.2%}   per sim: '
+          f'epilogue {st[:,2].mean()/tot:.2%}  expand+backup {st[:,3].mean()/tot:.2%}  [select, dense, sts, backup, stage-in, minmax] per sim: '
           + ' '.join(f'{x/50:.0f}' for x in st.mean(0)))
