@@ -51,9 +51,19 @@ struct Dev {
     unsigned long long seed, tree_id0;
 };
 
-__device__ __forceinline__ char *node_rec(const Dev &d, int t, int n)
+// Where one tree's records and descent path live while a kernel works on it: its slices of the
+// global arrays, or a copy in the block's LDS (whole-search kernels over small trees).
+struct TreeMem {
+    char *nodes;    // [N][rec]
+    int32_t *path;  // [S]
+};
+
+__device__ __forceinline__ TreeMem tree_mem(const Dev &d, int t)
 {
-    return d.nodes + (long long)t * d.L.tree_stride + (long long)n * d.L.rec;
+    TreeMem m;
+    m.nodes = d.nodes + (long long)t * d.L.tree_stride;
+    m.path = d.path + (long long)t * d.L.S;
+    return m;
 }
 
 // ----------------------------------------------------------------- group collectives

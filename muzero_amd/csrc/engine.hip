@@ -59,7 +59,7 @@ template <int LANES, bool GUMBEL>
 __device__ __forceinline__ void write_root(const Dev &d, int t, int a, bool on, double prior, double val,
                                            int to_play, bool is_legal, double gumbel_a, int max_considered)
 {
-    RowView w = view(d, t, 0);
+    RowView w = view(d, tree_mem(d, t), 0);
     if (a == 0) {
         NodeHdr h;
         h.visits = 1; h.parent = -1; h.afp = -1; h.to_play = to_play; h.value = val; h.raw = val;
@@ -127,8 +127,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_select(Dev d, const double *noise,
     const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
     int action, ntp, depth;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
-    int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
+    int parent = descend<LANES, RL, GUMBEL>(d, dc, tree_mem(d, t), a, on, nz, noise_max_calls, calls, &action, &ntp,
+                                            &depth);
     if (a == 0) {
+        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
         d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
         if (out_parent) out_parent[t] = parent;
         if (out_action) out_action[t] = action;
@@ -154,8 +157,9 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_expand_backup(Dev d, int leaf, con
         return;
     }
     float lg = on ? logits[(long long)t * d.L.A + a] : 0.0f;
-    expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t],
+    expand_backup<LANES, GUMBEL>(d, tree_mem(d, t), a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t],
                                  s_bk + (threadIdx.x / LANES) * LANES);
+    if (a == 0) d.visit_total[t] += depth + 1;
     if (next_hidden) {
         float *dst = d.hidden + ((long long)t * d.L.N + leaf) * d.L.H;
         for (int i = a; i < d.L.H; i += LANES) dst[i] = next_hidden[(long long)t * d.L.H + i];
@@ -181,20 +185,28 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int
     float *hid = d.hidden + (long long)t * d.L.N * H;
     double *bk = s_bk + (threadIdx.x / LANES) * LANES;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
+    const TreeMem m = tree_mem(d, t);
+    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
+    long long visited = 0;
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
         int action, ntp, depth;
-        int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+        int parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+        visited += depth + 1;
         const float *ph = hid + (long long)parent * H;
         uint32_t pcode = (uint32_t)ph[0] | ((uint32_t)ph[1] << 16);
         uint32_t ccode = hash2(pcode, 300 + action);
         uint32_t src = hn.parent_predicts ? pcode : ccode;
         float lg = on ? hash_logit(src, a, hn.logit_shift) : 0.0f;
-        expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, hash_value(src),
+        expand_backup<LANES, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, hash_value(src),
                                      hash_reward(ccode, hn.reward_on), bk);
         float *dst = hid + (long long)leaf * H;
         for (int i = a; i < H; i += LANES) dst[i] = hash_hidden(ccode, i);
         __threadfence_block();  // this group's stores are read by its other lanes in the next descent
+    }
+    if (a == 0) {
+        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        d.visit_total[t] += visited;
     }
 }
 
@@ -403,10 +415,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_begin_net(Dev d, RootNetDev rn, co
     if (out_value && a == 0) out_value[t] = value;
 }
 
-template <int LANES, int RL, bool GUMBEL>
+// TREE_LDS: each group's node records, hidden states and path live in LDS for the whole search (staged in
+// at the start, written back at the end); `tree_lds_bytes` is the per-group size of that region.
+template <int LANES, int RL, bool GUMBEL, bool TREE_LDS>
 __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int first_leaf, int n_sims,
                                                           const double *noise, int noise_max_calls,
-                                                          int scratch_floats)
+                                                          int scratch_floats, int tree_lds_bytes)
 {
     extern __shared__ __align__(16) float lds[];
     float *w = lds;                                                  // [n_data]
@@ -428,8 +442,28 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     bool on = a < A;
     const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
     float *hid = d.hidden + (long long)t * d.L.N * H;
+    float *const hid_global = hid;
+    TreeMem m = tree_mem(d, t);
+    const TreeMem m_global = m;
+    if constexpr (TREE_LDS) {
+        // region after the groups' activation scratch, 16-byte aligned: records | hidden | path
+        size_t base = ((size_t)(net.n_data + net.n_meta) + (size_t)(MZ_BLOCK / LANES) * scratch_floats) * 4;
+        base = (base + 15) & ~(size_t)15;
+        char *tl = reinterpret_cast<char *>(lds) + base + (size_t)(threadIdx.x / LANES) * tree_lds_bytes;
+        const int rec_bytes = (d.L.N * d.L.rec + 15) & ~15, hid_bytes = (d.L.N * H * 4 + 15) & ~15;
+        m.nodes = tl;
+        hid = reinterpret_cast<float *>(tl + rec_bytes);
+        m.path = reinterpret_cast<int32_t *>(tl + rec_bytes + hid_bytes);
+        const int32_t *src = reinterpret_cast<const int32_t *>(m_global.nodes);
+        int32_t *dst = reinterpret_cast<int32_t *>(m.nodes);
+        for (int i = a; i < first_leaf * (d.L.rec / 4); i += LANES) dst[i] = src[i];
+        for (int i = a; i < first_leaf * H; i += LANES) hid[i] = hid_global[i];
+        lds_fence();
+    }
     double *bk = s_bk + (threadIdx.x / LANES) * LANES;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
+    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
+    long long visited = 0;
     const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
 #ifdef MZ_STAMPS
     long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_in = 0, st_mm = 0, st_t;
@@ -441,7 +475,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
         int action, ntp, depth;
-        int parent = descend<LANES, RL, GUMBEL>(d, dc, t, a, on, nz, noise_max_calls, &action, &ntp, &depth);
+        int parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+        visited += depth + 1;
         MZ_STAMP(st_sel)
         // inputs: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
         const float *ph = hid + (long long)parent * H;
@@ -457,9 +492,21 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         support_to_scalar2<LANES>(sc + net.io[5], sc + net.io[3], sup, a, &value, &reward);
         float lg = on ? sc[net.io[4] + a] : 0.0f;
         MZ_STAMP(st_epi)
-        expand_backup<LANES, GUMBEL>(d, t, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
-        __threadfence_block();
+        expand_backup<LANES, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
+        if constexpr (TREE_LDS) lds_fence();
+        else __threadfence_block();
         MZ_STAMP(st_bk)
+    }
+    if (a == 0) {
+        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        d.visit_total[t] += visited;
+    }
+    if constexpr (TREE_LDS) {
+        const int live = first_leaf + n_sims;
+        const int32_t *src = reinterpret_cast<const int32_t *>(m.nodes);
+        int32_t *dst = reinterpret_cast<int32_t *>(m_global.nodes);
+        for (int i = a; i < live * (d.L.rec / 4); i += LANES) dst[i] = src[i];
+        for (int i = a; i < live * H; i += LANES) hid_global[i] = hid[i];
     }
 #ifdef MZ_STAMPS
     if (a == 0) {  // diagnostic build only: cycle shares per phase, parked in the path buffer (dead after the search)
@@ -477,7 +524,7 @@ __device__ __forceinline__ int to_act_rule(const Dev &d, int t, int a, bool on, 
 {
     const int A = d.L.A;
     const double inf = __builtin_huge_val();
-    NodeStats s = load_node<GUMBEL>(d, t, 0, a, on);
+    NodeStats s = load_node<GUMBEL>(d, tree_mem(d, t), 0, a, on);
     bool legal = (d.legal[t] >> a) & 1ull;
     int action;
     double prob, qout;
@@ -691,11 +738,11 @@ __global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int dept
         int child;
         double u = (uniform && on) ? uniform[a] : 0.0;
         DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, nullptr);
-        int act = select_at<RL, GUMBEL>(d, dc, t, node, depth, a, on, u, &child);
+        int act = select_at<RL, GUMBEL>(d, dc, tree_mem(d, t), node, depth, a, on, u, &child);
         if (a == 0) *out_action = act;
         return;
     }
-    NodeStats s = load_node<GUMBEL>(d, t, node, a, on);
+    NodeStats s = load_node<GUMBEL>(d, tree_mem(d, t), node, a, on);
     double r;
     if (which == 0) {
         r = qt_parent_siblings<RL>(d, s, on);
@@ -719,12 +766,13 @@ __global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int dept
 __global__ void k_node_backward(Dev d, int t, int leaf, int to_play)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double leaf_value = view(d, t, leaf).hdr->value;
+    const TreeMem m = tree_mem(d, t);
+    double leaf_value = view(d, m, leaf).hdr->value;
     for (int guard = 0; leaf != 0 && guard <= d.L.S; guard++) {
-        RowView lf = view(d, t, leaf);
+        RowView lf = view(d, m, leaf);
         int p = lf.hdr->parent, a = lf.hdr->afp;
         if (p < 0 || p >= d.L.N || a < 0 || a >= d.L.A) { atomicExch(d.err, 1); return; }
-        RowView pw = view(d, t, p);
+        RowView pw = view(d, m, p);
         double reward = pw.crew[a];
         int pv = pw.hdr->visits;
         double sv = pw.hdr->to_play == to_play ? leaf_value : -leaf_value;
@@ -1072,14 +1120,29 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         size_t lds = ((size_t)c->net.n_data + c->net.n_meta + (size_t)(MZ_BLOCK / c->lanes) * c->net_scratch) * 4;
         if (lds > 160 * 1024)
             return fail(MZ_ERR_ARG, "mz_search_run: network does not fit in LDS for the fused search; use the step API");
+        // Small batches are latency-bound: whole-wave groups keep their trees in LDS when one block per CU
+        // covers the batch and everything fits beside the kernel's static tables.
+        const Layout &L = c->d.L;
+        const int tree_lds = ((L.N * L.rec + 15) & ~15) + ((L.N * L.H * 4 + 15) & ~15) + ((L.S * 4 + 15) & ~15);
+        const size_t lds_tree = ((lds + 15) & ~(size_t)15) + (size_t)(MZ_BLOCK / c->lanes) * tree_lds;
+        const size_t lds_static = (size_t)MZ_BLOCK * 8 + (c->cfg.gumbel ? 32 : (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8);
+        bool tree_in_lds = c->lanes == 64 && grid_for(c->B, 64) <= 256 && lds_tree + lds_static <= 160 * 1024;
+        if (const char *e = getenv("MZ_TREE_LDS")) tree_in_lds = tree_in_lds && atoi(e) != 0;
         hipError_t attr_err = hipSuccess;
         dispatch_shape(c->lanes, c->rl, c->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) {
-            auto kern = k_search_net<decltype(L_)::value, decltype(R_)::value, decltype(G_)::value>;
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(grid_for(c->B, decltype(L_)::value)), dim3(MZ_BLOCK), lds,
-                               (hipStream_t)stream, c->d, c->net, c->n_expanded + 1, n_sims, noise,
-                               (int)noise_max_calls, c->net_scratch);
+            constexpr int LN = decltype(L_)::value, RN = decltype(R_)::value;
+            constexpr bool GM = decltype(G_)::value;
+            auto launch = [&](auto kern, size_t bytes, int tree_bytes) {
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+                hipLaunchKernelGGL(kern, dim3(grid_for(c->B, LN)), dim3(MZ_BLOCK), bytes, (hipStream_t)stream, c->d,
+                                   c->net, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch,
+                                   tree_bytes);
+            };
+            if constexpr (LN == 64) {
+                if (tree_in_lds) { launch(k_search_net<LN, RN, GM, true>, lds_tree, tree_lds); return; }
+            }
+            launch(k_search_net<LN, RN, GM, false>, lds, 0);
         });
         if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
         c->n_expanded += n_sims;

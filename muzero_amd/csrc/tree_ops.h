@@ -13,9 +13,9 @@ struct RowView {
     int32_t *cvis, *cidx;
 };
 
-__device__ __forceinline__ RowView view(const Dev &d, int t, int n)
+__device__ __forceinline__ RowView view(const Dev &d, const TreeMem &m, int n)
 {
-    char *r = node_rec(d, t, n);
+    char *r = m.nodes + n * d.L.rec;
     RowView v;
     v.hdr = reinterpret_cast<NodeHdr *>(r);
     v.cval = reinterpret_cast<double *>(r + d.L.off_cval);
@@ -35,9 +35,9 @@ struct NodeStats {  // what lane `a` holds of the node being scored
 };
 
 template <bool GUMBEL>
-__device__ __forceinline__ NodeStats load_node(const Dev &d, int t, int node, int a, bool on)
+__device__ __forceinline__ NodeStats load_node(const Dev &d, const TreeMem &m, int node, int a, bool on)
 {
-    RowView w = view(d, t, node);
+    RowView w = view(d, m, node);
     NodeStats s;
     s.nv = w.hdr->visits;
     s.nval = w.hdr->value;
@@ -149,11 +149,11 @@ __device__ __forceinline__ DescendCtx descend_ctx(const Dev &d, int t, int a, bo
 // :73-96 Gumbel root; :99-118 Gumbel interior).  `u` is this lane's tie-break uniform (PUCT).
 // LANES here is the number of action lanes (RL) of the group; only those lanes call it.
 template <int LANES, bool GUMBEL>
-__device__ __forceinline__ int select_at(const Dev &d, const DescendCtx &c, int t, int node, int depth, int a,
+__device__ __forceinline__ int select_at(const Dev &d, const DescendCtx &c, const TreeMem &m, int node, int depth, int a,
                                          bool on, double u, int *child_out)
 {
     const double inf = __builtin_huge_val();
-    NodeStats s = load_node<GUMBEL>(d, t, node, a, on);
+    NodeStats s = load_node<GUMBEL>(d, m, node, a, on);
     bool legal = depth != 0 || ((c.legal >> a) & 1ull);
     double score;
     if constexpr (!GUMBEL) {
@@ -185,15 +185,16 @@ __device__ __forceinline__ int select_at(const Dev &d, const DescendCtx &c, int 
 // MCTS.simulate, mcts/mcts.py:98-114.  Returns the parent node; action/next_to_play/depth by reference.
 // Records the path for the backup.  noise: MZ_NOISE_BUFFER rows for this tree, or NULL.
 // The RL action lanes walk the tree; the result is then shared with the rest of the group.
+// `calls`: PUCT selection calls made so far in this search (indexes the tie-break noise); advanced here
+// on the action lanes.
 template <int LANES, int RL, bool GUMBEL>
-__device__ __forceinline__ int descend(const Dev &d, const DescendCtx &c, int t, int a, bool on,
-                                       const double *noise, int noise_max_calls, int *action_out, int *ntp_out,
-                                       int *depth_out)
+__device__ __forceinline__ int descend(const Dev &d, const DescendCtx &c, const TreeMem &m, int a, bool on,
+                                       const double *noise, int noise_max_calls, uint32_t &calls, int *action_out,
+                                       int *ntp_out, int *depth_out)
 {
     int node = 0, depth = 0, ntp = 0, action = 0;
     if (LANES == RL || a < RL) {
-        uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-        int32_t *path = d.path + (long long)t * d.L.S;
+        int32_t *path = m.path;
         while (true) {
             double u = 0.0;
             if constexpr (!GUMBEL) {
@@ -205,14 +206,13 @@ __device__ __forceinline__ int descend(const Dev &d, const DescendCtx &c, int t,
                 calls++;
             }
             int child;
-            action = select_at<RL, GUMBEL>(d, c, t, node, depth, a, on, u, &child);
+            action = select_at<RL, GUMBEL>(d, c, m, node, depth, a, on, u, &child);
             if (a == 0 && depth < d.L.S) path[depth] = (node << 6) | action;
             ntp = d.players == 1 ? ntp : 1 - ntp;
             depth++;
             if (child < 0 || depth > d.L.S) break;  // depth bound: a malformed tree cannot spin forever
             node = child;
         }
-        if constexpr (!GUMBEL) { if (a == 0) d.noise_calls[t] = calls; }
     }
     if constexpr (RL < LANES) {  // lanes beyond the action lanes take lane 0's result
         int packed = (node << 6) | action;
@@ -228,17 +228,17 @@ __device__ __forceinline__ int descend(const Dev &d, const DescendCtx &c, int t,
 // recorded path.  `logit` is this lane's prior logit; value/reward are group-uniform.
 // `lds_r`: LANES doubles of LDS owned by this group (staging of the per-level rewards).
 template <int LANES, bool GUMBEL>
-__device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool on, int parent, int action,
+__device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, int a, bool on, int parent, int action,
                                               int ntp, int depth, int leaf, float logit, double value,
                                               double reward, double *lds_r)
 {
     // --- expansion: a fresh record for the leaf, links in the parent
-    RowView lf = view(d, t, leaf);
+    RowView lf = view(d, m, leaf);
     if (a == 0) {
         NodeHdr h;
         h.visits = 1; h.parent = parent; h.afp = action; h.to_play = ntp; h.value = value; h.raw = value;
         *lf.hdr = h;
-        RowView pr = view(d, t, parent);
+        RowView pr = view(d, m, parent);
         pr.cidx[action] = leaf;
         pr.crew[action] = reward;
     }
@@ -250,7 +250,7 @@ __device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool o
     // --- backup: lane i of a chunk owns level i above the leaf; loads are independent, only the
     // discounted return L is a serial recurrence (reward + gamma * L, mcts/mcts.py:162), which every
     // lane replays from the rewards staged in LDS (reads run ahead of the dependent multiply-add chain).
-    const int32_t *path = d.path + (long long)t * d.L.S;
+    const int32_t *path = m.path;
     double L = value, carry = value;
     for (int base = 0; base < depth; base += LANES) {
         int i = base + a;
@@ -261,7 +261,7 @@ __device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool o
         if (valid) {
             int pk = path[depth - 1 - i];
             p = pk >> 6; pa = pk & 63;
-            pw = view(d, t, p);
+            pw = view(d, m, p);
             nv = pw.hdr->visits; V = pw.hdr->value; tp = pw.hdr->to_play;
             r = i == 0 ? reward : pw.crew[pa];
             cvs = pw.cvis[pa];
@@ -301,7 +301,6 @@ __device__ __forceinline__ void expand_backup(const Dev &d, int t, int a, bool o
             pw.cvis[pa] = cvs + 1;
         }
     }
-    if (a == 0) d.visit_total[t] += depth + 1;
 }
 
 // mcts/mcts.py:22-31 + utils/game_utils.py:71-78: this lane's prepared root prior logit from the
