@@ -56,6 +56,7 @@ struct Dev {
 struct TreeMem {
     char *nodes;    // [N][rec]
     int32_t *path;  // [S]
+    int32_t *depth; // [N] depth of every live node (LDS-resident trees only), else NULL
 };
 
 __device__ __forceinline__ TreeMem tree_mem(const Dev &d, int t)
@@ -63,6 +64,7 @@ __device__ __forceinline__ TreeMem tree_mem(const Dev &d, int t)
     TreeMem m;
     m.nodes = d.nodes + (long long)t * d.L.tree_stride;
     m.path = d.path + (long long)t * d.L.S;
+    m.depth = nullptr;
     return m;
 }
 

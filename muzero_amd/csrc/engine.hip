@@ -454,12 +454,20 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         m.nodes = tl;
         hid = reinterpret_cast<float *>(tl + rec_bytes);
         m.path = reinterpret_cast<int32_t *>(tl + rec_bytes + hid_bytes);
+        m.depth = m.path + ((d.L.S + 3) & ~3);
         const int32_t *src = reinterpret_cast<const int32_t *>(m_global.nodes);
         int32_t *dst = reinterpret_cast<int32_t *>(m.nodes);
         for (int i = a; i < first_leaf * (d.L.rec / 4); i += LANES) dst[i] = src[i];
         for (int i = a; i < first_leaf * H; i += LANES) hid[i] = hid_global[i];
         lds_fence();
+        if (a == 0) {  // parents precede their children, so one forward sweep gives every depth
+            m.depth[0] = 0;
+            for (int n = 1; n < first_leaf; n++) m.depth[n] = m.depth[view(d, m, n).hdr->parent] + 1;
+        }
+        lds_fence();
     }
+    constexpr bool WIDE = TREE_LDS && LANES == 64 && RL == 2;
+    const bool wide = WIDE && d.L.N <= 2 * (64 / RL);
     double *bk = s_bk + (threadIdx.x / LANES) * LANES;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
@@ -475,7 +483,9 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     for (int s = 0; s < n_sims; s++) {
         int leaf = first_leaf + s;
         int action, ntp, depth;
-        int parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+        int parent;
+        if (wide) parent = descend_wide<RL, GUMBEL>(d, dc, m, a, leaf, nz, noise_max_calls, calls, &action, &ntp, &depth);
+        else parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
         visited += depth + 1;
         MZ_STAMP(st_sel)
         // inputs: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
@@ -1123,7 +1133,8 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         // Small batches are latency-bound: whole-wave groups keep their trees in LDS when one block per CU
         // covers the batch and everything fits beside the kernel's static tables.
         const Layout &L = c->d.L;
-        const int tree_lds = ((L.N * L.rec + 15) & ~15) + ((L.N * L.H * 4 + 15) & ~15) + ((L.S * 4 + 15) & ~15);
+        const int tree_lds = ((L.N * L.rec + 15) & ~15) + ((L.N * L.H * 4 + 15) & ~15) + ((L.S * 4 + 15) & ~15) +
+                             ((L.N * 4 + 15) & ~15);
         const size_t lds_tree = ((lds + 15) & ~(size_t)15) + (size_t)(MZ_BLOCK / c->lanes) * tree_lds;
         const size_t lds_static = (size_t)MZ_BLOCK * 8 + (c->cfg.gumbel ? 32 : (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8);
         bool tree_in_lds = c->lanes == 64 && grid_for(c->B, 64) <= 256 && lds_tree + lds_static <= 160 * 1024;

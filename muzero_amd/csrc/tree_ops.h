@@ -125,7 +125,8 @@ __device__ __forceinline__ double gumbel_score(const NodeStats &s, bool on, doub
 struct DescendCtx {
     unsigned long long legal;     // root legality mask of the tree
     unsigned long long key;       // counter-noise key of the tree
-    const double *c_table;        // exploration constants (LDS copy when the kernel staged one)
+    const double *c_table;        // exploration constants in global memory
+    const double *c_table_lds;    // LDS copy of the whole table when the kernel staged one, else NULL
     const double *sq_table;       // sqrt(n / (1 + c)) table in LDS, or NULL
     const int32_t *cv_row;        // sequential-halving schedule of this tree's considered count
     double gumbel_a;              // this lane's Gumbel noise
@@ -139,7 +140,8 @@ __device__ __forceinline__ DescendCtx descend_ctx(const Dev &d, int t, int a, bo
     c.sq_table = sq_table_lds;
     c.legal = d.legal[t];
     c.key = GUMBEL ? 0ull : noise_key(d.seed, d.tree_id0 + (unsigned long long)t);
-    c.c_table = c_table_lds ? c_table_lds : d.c_table;
+    c.c_table = d.c_table;
+    c.c_table_lds = c_table_lds;
     c.cv_row = GUMBEL ? d.cv_table + (long long)d.m_considered[t] * d.L.S : nullptr;
     c.gumbel_a = (GUMBEL && on) ? d.gumbel[(long long)t * d.L.A + a] : 0.0;
     return c;
@@ -158,7 +160,8 @@ __device__ __forceinline__ int select_at(const Dev &d, const DescendCtx &c, cons
     double score;
     if constexpr (!GUMBEL) {
         double nq = qt_parent_siblings<LANES>(d, s, on);
-        double cc = c.c_table[s.nv];
+        // two typed loads (LDS or global) instead of one through a generic pointer
+        double cc = c.c_table_lds ? c.c_table_lds[s.nv] : c.c_table[s.nv];
         // sqrt(N / (1 + n_a)): integer arguments, so a table of the correctly rounded values is bit-identical
         double sq = c.sq_table ? c.sq_table[s.nv * (d.L.S + 1) + s.cv] : sqrt((double)s.nv / (double)(1 + s.cv));
         double uu = cc * s.prior + sq;
@@ -224,6 +227,55 @@ __device__ __forceinline__ int descend(const Dev &d, const DescendCtx &c, const 
     return node;
 }
 
+// The same descent for a whole-wave group over a tree of at most 2 * (64 / RL) nodes whose records sit
+// in LDS: every live node's selection is evaluated at once (RL lanes per node; the decision at a node is
+// a pure function of its statistics and of the tie-break noise of call `calls + depth(node)`), then the
+// path is read off the per-node results with lane reads.  Same results as descend().
+template <int RL, bool GUMBEL>
+__device__ __forceinline__ int descend_wide(const Dev &d, const DescendCtx &c, const TreeMem &m, int lane, int n_live,
+                                            const double *noise, int noise_max_calls, uint32_t &calls,
+                                            int *action_out, int *ntp_out, int *depth_out)
+{
+    constexpr int NP = 64 / RL;  // nodes per pass
+    const int a = lane % RL, slot = lane / RL;
+    const bool on = a < d.L.A;
+    int pack[2] = {0, 0};        // per node: (child + 1) << 8 | action, held by the node's lanes
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        if (p * NP >= n_live) break;
+        int node = p * NP + slot;
+        const bool live = node < n_live;
+        node = live ? node : 0;  // spare lanes redo the root so that every load stays on initialised records
+        const int dn = m.depth[node];
+        double u = 0.0;
+        if constexpr (!GUMBEL) {
+            const uint32_t call = calls + (uint32_t)dn;
+            if (on) {
+                if (d.noise_mode == 0) u = noise_from_key(c.key, call, (unsigned)a);
+                else if (d.noise_mode == 1 && (int)call < noise_max_calls) u = noise[(long long)call * d.L.A + a];
+            }
+        }
+        int child;
+        int act = select_at<RL, GUMBEL>(d, c, m, node, dn, a, on, u, &child);
+        pack[p] = ((child + 1) << 8) | act;
+    }
+    int node = 0, depth = 0, ntp = 0, action = 0;
+    while (true) {
+        int pk = node < NP ? __builtin_amdgcn_readlane(pack[0], node * RL)
+                           : __builtin_amdgcn_readlane(pack[1], (node - NP) * RL);
+        action = pk & 0xff;
+        int child = (pk >> 8) - 1;
+        if (lane == 0 && depth < d.L.S) m.path[depth] = (node << 6) | action;
+        ntp = d.players == 1 ? ntp : 1 - ntp;
+        depth++;
+        if (child < 0 || child >= n_live || depth > d.L.S) break;
+        node = child;
+    }
+    calls += (uint32_t)depth;
+    *action_out = action; *ntp_out = ntp; *depth_out = depth;
+    return node;
+}
+
 // MCTS.expand (mcts/mcts.py:116-141) for leaf index `leaf`, then MCTS.backward (:143-164) along the
 // recorded path.  `logit` is this lane's prior logit; value/reward are group-uniform.
 // `lds_r`: LANES doubles of LDS owned by this group (staging of the per-level rewards).
@@ -238,6 +290,7 @@ __device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, in
         NodeHdr h;
         h.visits = 1; h.parent = parent; h.afp = action; h.to_play = ntp; h.value = value; h.raw = value;
         *lf.hdr = h;
+        if (m.depth) m.depth[leaf] = depth;
         RowView pr = view(d, m, parent);
         pr.cidx[action] = leaf;
         pr.crew[action] = reward;
