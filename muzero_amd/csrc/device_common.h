@@ -234,6 +234,36 @@ __device__ __forceinline__ double wave_reduce(double v, double ident, F f)
     int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
+// Reduction over each half of the wave (lanes 0-31 and 32-63 separately); every lane gets its half's result.
+template <typename F>
+__device__ __forceinline__ float half_reduce(float v, float ident, bool upper, F f)
+{
+    v = f(v, dpp_mov<MZ_DPP_XOR1>(v));
+    v = f(v, dpp_mov<MZ_DPP_XOR2>(v));
+    v = f(v, dpp_mov<MZ_DPP_HALF_MIRROR>(v));
+    v = f(v, dpp_mov<MZ_DPP_MIRROR>(v));
+    v = f(v, dpp_masked<0x142, 0xA>(ident, v));  // rows 1 and 3 now hold their half's result
+    int b = __builtin_bit_cast(int, v);
+    int lo = __builtin_amdgcn_readlane(b, 31), hi = __builtin_amdgcn_readlane(b, 63);
+    return __builtin_bit_cast(float, upper ? hi : lo);
+}
+template <typename F>
+__device__ __forceinline__ double half_reduce(double v, double ident, bool upper, F f)
+{
+    v = f(v, dpp_mov<MZ_DPP_XOR1>(v));
+    v = f(v, dpp_mov<MZ_DPP_XOR2>(v));
+    v = f(v, dpp_mov<MZ_DPP_HALF_MIRROR>(v));
+    v = f(v, dpp_mov<MZ_DPP_MIRROR>(v));
+    long long x = __builtin_bit_cast(long long, v), ib = __builtin_bit_cast(long long, ident);
+    int l = __builtin_amdgcn_update_dpp((int)ib, (int)x, 0x142, 0xA, 0xF, false);
+    int h = __builtin_amdgcn_update_dpp((int)(ib >> 32), (int)(x >> 32), 0x142, 0xA, 0xF, false);
+    v = f(v, __builtin_bit_cast(double, ((long long)h << 32) | (unsigned)l));
+    x = __builtin_bit_cast(long long, v);
+    int lo0 = __builtin_amdgcn_readlane((int)x, 31), hi0 = __builtin_amdgcn_readlane((int)(x >> 32), 31);
+    int lo1 = __builtin_amdgcn_readlane((int)x, 63), hi1 = __builtin_amdgcn_readlane((int)(x >> 32), 63);
+    long long r = upper ? (((long long)hi1 << 32) | (unsigned)lo1) : (((long long)hi0 << 32) | (unsigned)lo0);
+    return __builtin_bit_cast(double, r);
+}
 __device__ __forceinline__ double wave_lane(double v, int lane)  // lane: compile-time-constant lane index
 {
     long long b = __builtin_bit_cast(long long, v);

@@ -238,6 +238,23 @@ __device__ __forceinline__ void support_to_scalar2(const float *lgA, const float
                                                    double *outA, double *outB)
 {
     const int L = (n - 1) / 2;
+    if constexpr (LANES == 64) {
+        if (n <= 32) {  // one vector per half of the wave: a single set of half-wave reductions serves both
+            const bool up = a >= 32;
+            const int i = a & 31;
+            const float ninf = -__builtin_huge_valf();
+            float v = i < n ? (up ? lgB : lgA)[i] : ninf;
+            float m = half_reduce(v, ninf, up, [](float x, float y) { return y > x ? y : x; });
+            float e = i < n ? expf(v - m) : 0.0f;
+            float sum = half_reduce(e, 0.0f, up, [](float x, float y) { return x + y; });
+            double x = i < n ? (double)(e / sum) * (double)(i - L) : 0.0;
+            x = half_reduce(x, 0.0, up, [](double p, double q) { return p + q; });
+            double y = inv_value_transform(x);
+            *outA = wave_lane(y, 0);
+            *outB = wave_lane(y, 32);
+            return;
+        }
+    }
     int W = 2;
     while (W < n && W < LANES) W <<= 1;  // lanes that hold elements
     const bool single = n <= LANES;      // one element per lane: keep it in registers
@@ -336,6 +353,86 @@ __device__ __forceinline__ void dense_run(const int32_t *meta, const float *w, f
     }
 }
 
+// A program of at most MAXL levels whose levels have at most one row per lane and at most 4 * MAXK4
+// inputs: each lane keeps its row's descriptor, bias and weights in registers across evaluations, so an
+// evaluation only reads the inputs from LDS.  Same operation order as dense_run.
+template <int MAXL, int MAXK4>
+struct DenseRegs {
+    int4 ds[MAXL];
+    float bias[MAXL];
+    float4 w[MAXL][MAXK4];
+    int k4n[MAXL];
+    int n_levels;
+};
+
+template <int LANES, int MAXL, int MAXK4>
+__device__ __forceinline__ bool dense_cacheable(const int32_t *meta)
+{
+    if (meta[0] > MAXL) return false;
+    const int32_t *lv = meta + meta[5];
+    for (int l = 0; l < meta[0]; l++)
+        if (lv[4 * l] > LANES || lv[4 * l + 1] > 4 * MAXK4) return false;
+    return true;
+}
+
+template <int LANES, int MAXL, int MAXK4>
+__device__ __forceinline__ void dense_cache_load(const int32_t *meta, const float *w, int a, DenseRegs<MAXL, MAXK4> &c)
+{
+    const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
+    const float *bias = w + meta[4];
+    c.n_levels = meta[0];
+#pragma unroll
+    for (int l = 0; l < MAXL; l++) {
+        c.ds[l] = make_int4(0, -1, 0, -1);
+        c.bias[l] = 0.0f;
+        c.k4n[l] = 0;
+#pragma unroll
+        for (int k = 0; k < MAXK4; k++) c.w[l][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < c.n_levels) {
+            const int n_rows = lv[4 * l], row0 = lv[4 * l + 3];
+            const float4 *W4 = reinterpret_cast<const float4 *>(w + lv[4 * l + 2]);
+            c.k4n[l] = lv[4 * l + 1] >> 2;
+            if (a < n_rows) {
+                c.ds[l] = *reinterpret_cast<const int4 *>(rows + 4 * (row0 + a));
+                c.bias[l] = bias[row0 + a];
+#pragma unroll
+                for (int k = 0; k < MAXK4; k++)
+                    if (k < c.k4n[l]) c.w[l][k] = W4[k * n_rows + a];
+            }
+        }
+    }
+}
+
+template <int MAXL, int MAXK4>
+__device__ __forceinline__ void dense_run_cached(const DenseRegs<MAXL, MAXK4> &c, float *sc)
+{
+#pragma unroll
+    for (int l = 0; l < MAXL; l++) {
+        if (l < c.n_levels) {
+            const int4 ds = c.ds[l];
+            if (ds.y >= 0) {
+                const float4 *x4 = reinterpret_cast<const float4 *>(sc + ds.x);
+                float acc = c.bias[l];
+#pragma unroll
+                for (int k = 0; k < MAXK4; k++) {
+                    if (k < c.k4n[l]) {
+                        float4 wv = c.w[l][k], xv = x4[k];
+                        acc = fmaf(wv.x, xv.x, acc);
+                        acc = fmaf(wv.y, xv.y, acc);
+                        acc = fmaf(wv.z, xv.z, acc);
+                        acc = fmaf(wv.w, xv.w, acc);
+                    }
+                }
+                if (ds.w >= 0) acc += sc[ds.w];
+                if (ds.z == 1) acc = acc > 0.0f ? acc : 0.0f;
+                else if (ds.z == 2) acc = acc > 0.0f ? acc : expm1f(acc);
+                sc[ds.y] = acc;
+            }
+            lds_fence();
+        }
+    }
+}
+
 // utils/network_utils.py:132-158: per-group min-max scaling of `raw` (LDS) into `dst` (and `dst2` if given).
 template <int LANES>
 __device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, int a, float *dst, float *dst2)
@@ -348,8 +445,12 @@ __device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, 
         int W = 2;
         while (W < per && W < LANES) W <<= 1;
         if constexpr (LANES == 64) {
-            mn = wave_reduce(mn, __builtin_huge_valf(), [](float x, float y) { return y < x ? y : x; });
-            mx = wave_reduce(mx, -__builtin_huge_valf(), [](float x, float y) { return y > x ? y : x; });
+            if (W <= 16) {  // the values sit in one row of 16 lanes
+                mn = gminf<16>(mn, W); mx = gmaxf<16>(mx, W);
+            } else {
+                mn = wave_reduce(mn, __builtin_huge_valf(), [](float x, float y) { return y < x ? y : x; });
+                mx = wave_reduce(mx, -__builtin_huge_valf(), [](float x, float y) { return y > x ? y : x; });
+            }
         } else {
             mn = gminf<LANES>(mn, W); mx = gmaxf<LANES>(mx, W);
         }
@@ -473,6 +574,13 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
     long long visited = 0;
     const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
+    constexpr bool CAN_CACHE = LANES == 64;
+    DenseRegs<2, 4> regs;
+    bool cached = false;
+    if constexpr (CAN_CACHE) {
+        cached = dense_cacheable<LANES, 2, 4>(meta);
+        if (cached) dense_cache_load<LANES, 2, 4>(meta, w, a, regs);
+    }
 #ifdef MZ_STAMPS
     long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_in = 0, st_mm = 0, st_t;
 #define MZ_STAMP(acc) { long long n_ = clock64(); acc += n_ - st_t; st_t = n_; }
@@ -494,7 +602,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         for (int i = a; i < asz; i += LANES) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
         lds_fence();
         MZ_STAMP(st_in)
-        dense_run<LANES>(meta, w, sc, a);
+        if (CAN_CACHE && cached) dense_run_cached<2, 4>(regs, sc);
+        else dense_run<LANES>(meta, w, sc, a);
         MZ_STAMP(st_net)
         minmax_to<LANES>(sc + net.io[2], H, ngroups, a, hid + (long long)leaf * H, nullptr);
         MZ_STAMP(st_mm)

@@ -344,7 +344,9 @@ __device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, in
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         double newV = (V * (double)nv + (tp == ntp ? myL : -myL)) / (double)(nv + 1);
-        double below = __shfl_up(newV, 1, LANES);
+        double below;  // the level below's new mean: lane a - 1 (a register move inside a row of 16 lanes)
+        if (LANES <= 16 || cnt <= 16) below = dpp_mov<MZ_DPP_SHR(1)>(newV);
+        else below = __shfl_up(newV, 1, LANES);
         double child_new = a == 0 ? carry : below;
         if (base + LANES < depth) carry = gshfl<LANES>(newV, cnt - 1);
         if (valid) {
