@@ -1,0 +1,37 @@
+"""Turns the rocprofv3 outputs of scripts/profile_round.sh (under gpurun_out/) into the summaries kept
+under profiles/: per-workload kernel statistics (csv copied as is) and HBM bytes per launch of the
+dominant kernel.  Usage: python scripts/pmc_summary.py <tag> <round-name>"""
+import csv, glob, json, os, shutil, sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+DOMINANT = {'cfg2': 'k_search_net', 'cfg4s': 'k_search_net', 'cfg3h': 'k_search_hash'}
+NOTE = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py (5 steps), mean over the '
+        'kernel launches; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (counters are in KiB; gfx950 reports half of '
+        'the fetched bytes)')
+traffic, raw = {}, {}
+for w, kern in DOMINANT.items():
+    st = glob.glob(f'gpurun_out/{tag}_stats_{w}/**/*kernel_stats.csv', recursive=True)
+    if st:
+        shutil.copy(st[0], f'profiles/{rnd}_{w}_kernel_stats.csv')
+    if os.path.exists(f'gpurun_out/{tag}_stats_{w}.json'):
+        shutil.copy(f'gpurun_out/{tag}_stats_{w}.json', f'profiles/{rnd}_{w}_bench_under_rocprof.json')
+    vals = {}
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        files = glob.glob(f'gpurun_out/{tag}_pmc_{w}_{c}/**/*counter_collection.csv', recursive=True)
+        if not files:
+            continue
+        xs, name = [], None
+        for row in csv.DictReader(open(files[0])):
+            if kern in row['Kernel_Name'] and row['Counter_Name'] == c:
+                xs.append(float(row['Counter_Value']))
+                name = row['Kernel_Name'].split('(')[0]
+        if xs:
+            vals[c] = (sum(xs) / len(xs), len(xs), name)
+    raw[w] = vals
+    if len(vals) == 2:
+        f, wr = vals['FETCH_SIZE'][0], vals['WRITE_SIZE'][0]
+        traffic[w] = {'kernel': vals['FETCH_SIZE'][2], 'fetch_size_kb': f, 'write_size_kb': wr,
+                      'traffic_bytes_per_launch': (2 * f + wr) * 1024, 'method': NOTE}
+json.dump(raw, open(f'profiles/{rnd}_pmc_hbm_traffic_raw.json', 'w'), indent=1)
+json.dump(traffic, open('profiles/hbm_traffic.json', 'w'), indent=1)
+print(json.dumps(traffic, indent=1))
