@@ -228,6 +228,34 @@ int mz_act_env_step(mz_ctx *ctx, const mz_env_state *env_h, double temperature, 
                     int32_t *out_action, double *out_probs, double *out_root_value, float *out_obs_before,
                     float *out_reward, uint8_t *out_done, int32_t *out_to_play, void *stream);
 
+/* Finished games kept on the device, positions of game g at [game_offset[g], game_offset[g+1]): the
+ * fields of GameHistory (games/game.py:83-94) as flat arrays.  HOST struct of DEVICE pointers. */
+typedef struct mz_trajectories {
+    int32_t n_games, obs_size, n_actions, reserved;
+    const int64_t *game_offset;     /* [n_games + 1] */
+    const float *observations;      /* [T][obs_size] */
+    const int32_t *actions;         /* [T] */
+    const double *rewards;          /* [T] */
+    const int32_t *to_plays;        /* [T] */
+    const double *root_values;      /* [T] */
+    const double *probs;            /* [T][n_actions] action_probabilities */
+    const double *re_root_values;   /* [T] reanalysed_root_values, or NULL */
+    const double *re_probs;         /* [T][n_actions] reanalysed_action_probabilities, or NULL */
+    const uint8_t *has_reanalysed;  /* [n_games] 1 where save_reanalysed_stats was applied, or NULL */
+} mz_trajectories;
+
+/* Replaces the per-game body of ReplayBuffer.sample (replay_buffer.py:70-101) for n_samples sampled
+ * positions (game_idx[i], t[i]): GameHistory.stack_n_observations (games/game.py:120-160) ->
+ * out_obs f32[n][n_stack*(1+stack_action)*obs], the unrolled one-hot actions with absorbing padding ->
+ * out_actions f32[n][U+1][A] (absorbed i32[n][U+1]: the sampled earlier positions used past the end of
+ * a game, left-aligned), GameHistory.make_target (games/game.py:185-253) -> out_value, out_reward
+ * f32[n][U+1], out_policy f32[n][U+1][A].  gamma_pow: DEVICE f64[td_steps+1] = gamma**k as the host
+ * evaluates it.  All other pointers are device pointers; the sampling itself stays with the caller. */
+int mz_make_targets(const mz_trajectories *traj_h, int32_t n_samples, const int32_t *game_idx, const int32_t *t,
+                    const int32_t *absorbed, int32_t td_steps, int32_t unroll_steps, double gamma,
+                    const double *gamma_pow, int32_t n_stack, int32_t stack_action, float *out_obs,
+                    float *out_actions, float *out_value, float *out_reward, float *out_policy, void *stream);
+
 /* Sequential-halving schedule, mcts/action_selection.py:160-175 (host, pure integer). out_h i32[S]. */
 int mz_considered_visits(int32_t max_considered_actions, int32_t simulations, int32_t *out_h);
 

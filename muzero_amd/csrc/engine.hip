@@ -11,6 +11,7 @@
 #include "../../include/muzero_amd.h"
 #include "tree_ops.h"
 #include "net_mfma.h"
+#include "targets.h"
 
 using namespace mz;
 
@@ -1286,6 +1287,34 @@ extern "C" int mz_to_act(mz_ctx *c, double temperature, const double *u, int32_t
     if (!out_action || !out_probs || !out_root_value) return fail(MZ_ERR_ARG, "mz_to_act: null output");
     MZ_LAUNCH(c, k_to_act, true, c->B, 0, stream, c->d, temperature, u, out_action, out_probs, out_root_value, out_q);
     return launch_status("mz_to_act");
+}
+
+extern "C" int mz_make_targets(const mz_trajectories *tr, int32_t n_samples, const int32_t *game_idx, const int32_t *t,
+                               const int32_t *absorbed, int32_t td_steps, int32_t unroll_steps, double gamma,
+                               const double *gamma_pow, int32_t n_stack, int32_t stack_action, float *out_obs,
+                               float *out_actions, float *out_value, float *out_reward, float *out_policy,
+                               void *stream)
+{
+    (void)hipGetLastError();
+    if (!tr || n_samples < 1 || !game_idx || !t || !absorbed || !out_obs || !out_actions || !out_value || !out_reward ||
+        !out_policy)
+        return fail(MZ_ERR_ARG, "mz_make_targets: null/empty argument");
+    if (!tr->game_offset || !tr->observations || !tr->actions || !tr->rewards || !tr->to_plays || !tr->root_values ||
+        !tr->probs || tr->n_games < 1 || tr->obs_size < 1 || tr->n_actions < 1)
+        return fail(MZ_ERR_ARG, "mz_make_targets: incomplete trajectory store");
+    if (td_steps < 0 || unroll_steps < 0 || n_stack < 1) return fail(MZ_ERR_ARG, "mz_make_targets: bad step counts");
+    if (gamma != 1.0 && !gamma_pow) return fail(MZ_ERR_ARG, "mz_make_targets: gamma_pow table required when gamma != 1");
+    TrajDev d;
+    d.n_games = tr->n_games; d.obs_size = tr->obs_size; d.A = tr->n_actions;
+    d.game_offset = reinterpret_cast<const long long *>(tr->game_offset);
+    d.observations = tr->observations; d.actions = tr->actions; d.rewards = tr->rewards; d.to_plays = tr->to_plays;
+    d.root_values = tr->root_values; d.probs = tr->probs;
+    d.re_root_values = tr->re_root_values; d.re_probs = tr->re_probs; d.has_re = tr->has_reanalysed;
+    long long n = (long long)n_samples * (unroll_steps + 1);
+    hipLaunchKernelGGL(k_make_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d,
+                       (int)n_samples, game_idx, t, absorbed, (int)td_steps, (int)unroll_steps, gamma, gamma_pow,
+                       (int)n_stack, (int)stack_action, out_obs, out_actions, out_value, out_reward, out_policy);
+    return launch_status("mz_make_targets");
 }
 
 extern "C" int mz_stats(mz_ctx *c, int64_t *out_node_visits, int32_t *out_noise_calls, void *stream)

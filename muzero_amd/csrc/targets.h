@@ -1,0 +1,100 @@
+// Training-target construction over trajectories kept on the device (the caller side of the search:
+// what the reference's replay buffer does with the (action, root value, policy) records the search
+// produced).  One thread per (sample, unroll step); HBM-bound gathers, float64 sums in the
+// reference's order, float32 outputs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mz {
+
+struct TrajDev {
+    int n_games, obs_size, A;
+    const long long *game_offset;  // [G + 1]
+    const float *observations;     // [T][obs]
+    const int32_t *actions;        // [T]
+    const double *rewards;         // [T]
+    const int32_t *to_plays;       // [T]
+    const double *root_values, *probs;        // [T], [T][A]
+    const double *re_root_values, *re_probs;  // reanalysed statistics (may be NULL)
+    const uint8_t *has_re;                    // [G] (may be NULL)
+};
+
+// games/game.py:205-236: value target of position `step` of a game of length T starting at `o`.
+__device__ inline double value_target(const TrajDev &tr, long long o, int T, int step, int td, double gamma,
+                                      const double *gamma_pow, const double *root_values)
+{
+    if (step >= T) return 0.0;
+    const int me = tr.to_plays[o + step];
+    double sum = 0.0;
+    if (gamma == 1.0) {  // board games: signed sum of the rewards to the end of the game
+        for (int i = step; i < T; i++) {
+            double r = tr.rewards[o + i];
+            sum += tr.to_plays[o + i] == me ? r : -r;
+        }
+        return sum;
+    }
+    const int bs = step + td;
+    // rewards[step + 1 .. bootstrap_step], each signed by to_plays[step + k] (the index lags the reward's by one)
+    const int last = bs + 1 < T ? bs + 1 : T;
+    for (int i = step + 1, k = 0; i < last; i++, k++) {
+        double r = tr.rewards[o + i];
+        sum += (tr.to_plays[o + step + k] == me ? r : -r) * gamma_pow[k];
+    }
+    double bootstrap = 0.0;
+    if (bs < T) {
+        double v = root_values[o + bs];
+        bootstrap = (tr.to_plays[o + bs] == me ? v : -v) * gamma_pow[td];
+    }
+    return sum + bootstrap;
+}
+
+// replay_buffer.py:70-101 for one sampled (game, t): GameHistory.stack_n_observations (games/game.py:120-160),
+// the unrolled actions with absorbing padding, GameHistory.make_target (games/game.py:185-253).
+__global__ void k_make_targets(TrajDev tr, int n_samples, const int32_t *game_idx, const int32_t *ts,
+                               const int32_t *absorbed, int td, int unroll, double gamma, const double *gamma_pow,
+                               int n_stack, int stack_action, float *out_obs, float *out_actions,
+                               float *out_value, float *out_reward, float *out_policy)
+{
+    const int U1 = unroll + 1;
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)n_samples * U1) return;
+    const int b = (int)(gid / U1), k = (int)(gid % U1);
+    const int g = game_idx[b];
+    const long long o = tr.game_offset[g];
+    const int T = (int)(tr.game_offset[g + 1] - o);
+    const int t = ts[b], step = t + k, A = tr.A;
+    const bool re = tr.has_re && tr.has_re[g];
+    const double *rv = (re && tr.re_root_values) ? tr.re_root_values : tr.root_values;
+    const double *pr = (re && tr.re_probs) ? tr.re_probs : tr.probs;
+    double v = value_target(tr, o, T, step, td, gamma, gamma_pow, rv);
+    float *pol = out_policy + ((long long)b * U1 + k) * A;
+    if (step < T) {
+        out_value[(long long)b * U1 + k] = (float)v;
+        out_reward[(long long)b * U1 + k] = (float)tr.rewards[o + step];
+        for (int a = 0; a < A; a++) pol[a] = (float)pr[(o + step) * A + a];
+    } else {
+        out_value[(long long)b * U1 + k] = 0.0f;
+        out_reward[(long long)b * U1 + k] = 0.0f;
+        for (int a = 0; a < A; a++) pol[a] = (float)(1.0 / (double)A);
+    }
+    // action taken at t + k, or a uniformly sampled earlier action of the same game past its end
+    int src = step < T ? step : absorbed[(long long)b * U1 + (step - T)];
+    int act = tr.actions[o + src];
+    float *oa = out_actions + ((long long)b * U1 + k) * A;
+    for (int a = 0; a < A; a++) oa[a] = a == act ? 1.0f : 0.0f;
+    if (k == 0) {  // o_t, o_{t-1}, ... newest first, zero planes before the start of the game
+        const int planes = stack_action ? 2 : 1, OS = tr.obs_size;
+        float *oo = out_obs + (long long)b * n_stack * planes * OS;
+        for (int j = 0; j < n_stack; j++) {
+            const int s = t - j;
+            for (int i = 0; i < OS; i++) oo[(long long)(j * planes) * OS + i] = s >= 0 ? tr.observations[(o + s) * OS + i] : 0.0f;
+            if (stack_action) {
+                float av = s >= 0 ? (float)((double)tr.actions[o + s] / (double)A) : 0.0f;
+                for (int i = 0; i < OS; i++) oo[(long long)(j * planes + 1) * OS + i] = av;
+            }
+        }
+    }
+}
+
+}  // namespace mz

@@ -66,8 +66,8 @@ class MCTS:
     def search_batch(self, network, observations, legal_actions, to_play, temperature: float = 0,
                      action_encoder: Optional[Callable] = None, seed: int = 0, tree_id0: int = 0):
         """B independent positions at once.  Root noise (Gumbel / Dirichlet / the final sampling
-        uniform) is drawn from `np.random` per tree in batch order; the per-selection tie-break
-        uniforms are counter-based (`muzero_amd/noise.py`) keyed by (seed, tree_id0 + b)."""
+        uniform) is drawn from `np.random` tree by tree (PUCT: Dirichlet row then sampling uniform, like
+        consecutive reference searches); the per-selection tie-break uniforms are counter-based (`muzero_amd/noise.py`) keyed by (seed, tree_id0 + b)."""
         return self._search(network, observations, legal_actions, to_play, temperature, action_encoder,
                             stream_noise=False, seed=seed, tree_id0=tree_id0)
 
@@ -86,12 +86,20 @@ class MCTS:
         noise_mode = _engine.NOISE_BUFFER if (stream_noise and not gumbel) else _engine.NOISE_COUNTER
         eng = self._engine_for(H, B, noise_mode, seed)
         dev = eng.device
-        g = dirichlet = None
+        g = dirichlet = u_pre = None
         if gumbel:
             g = np.stack([np.random.gumbel(size=A) for _ in range(B)])
             prior = eng.root_prepare(logits.reshape(B, A), legal)
         else:
-            dirichlet = np.stack([np.random.dirichlet([cfg.dirichlet_alpha] * A) for _ in range(B)])
+            if stream_noise:
+                dirichlet = np.stack([np.random.dirichlet([cfg.dirichlet_alpha] * A) for _ in range(B)])
+            else:
+                # per tree: Dirichlet row, then the uniform of the final np.random.choice - the order in
+                # which B consecutive reference searches (tie-break uniforms aside) consume the stream
+                dirichlet, u_pre = np.empty((B, A)), np.empty(B)
+                for b in range(B):
+                    dirichlet[b] = np.random.dirichlet([cfg.dirichlet_alpha] * A)
+                    u_pre[b] = np.random.random_sample()
             prior = eng.root_prepare(logits.reshape(B, A), legal, dirichlet, cfg.exploration_frac)
         eng.reset(prior, value.reshape(B), hidden.reshape(B, H), np.asarray(to_play, dtype=np.int32).reshape(B),
                   legal, g, tree_id0=tree_id0)
@@ -121,7 +129,7 @@ class MCTS:
                 np.random.set_state(rng_state)
                 for n in calls.cpu().numpy():  # advance past the rows the search used
                     np.random.uniform(size=(int(n), A))
-            u = np.array([np.random.random_sample() for _ in range(B)])
+            u = u_pre if u_pre is not None else np.array([np.random.random_sample() for _ in range(B)])
         action, root_value, probs, _ = eng.to_act(float(temperature), u)
         self.last_engine = eng
         self._last_meta = (legal, g)

@@ -1,0 +1,64 @@
+"""Batched Reanalyse: every position of the sampled games is searched again in ONE batch.
+
+Mirrors the body of the reference's `Reanalyser.reanalyse` loop (reanalyse.py:44-79), which walks
+the positions of one game serially: stacked observations for all t, target-network values when
+`config.mcts_target_value` is false, a fresh search per position from a NEW game's legal mask
+(the actor's own game object is never stepped, reanalyse.py:69) with the recorded `to_plays[t]`,
+then `save_reanalysed_stats`.  Positions are independent, so they form one search batch.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .mcts.mcts import MCTS
+
+
+class BatchedReanalyser:
+    def __init__(self, game, config, target_network, seed: int = 0) -> None:
+        self.game = game            # only its fresh legal_actions() / action_encoder are used
+        self.config = config
+        self.target_network = target_network
+        self.mcts = MCTS(config)
+        self.seed = seed
+
+    def set_weights(self, network) -> None:
+        """Target-network refresh (reanalyse.py:38-42); the cadence is the caller's."""
+        self.target_network = network
+
+    def reanalyse_games(self, histories: Sequence, tree_id0: int = 0) -> List:
+        """Recomputes policies and values of every position of `histories` in place
+        (`save_reanalysed_stats`) and returns them; positions are batched in game order, and position
+        k of the batch uses tie-break noise key `tree_id0 + k`."""
+        cfg = self.config
+        stack = lambda h, t: h.stack_n_observations(t, cfg.n_stacked_observations, cfg.n_actions, cfg.stack_action)  # noqa: E731
+        obs, to_play, owner = [], [], []
+        for g, h in enumerate(histories):
+            for t in range(len(h)):
+                obs.append(np.asarray(stack(h, t), dtype=np.float64))
+                to_play.append(h.to_plays[t])
+                owner.append(g)
+        if not obs:
+            return []
+        obs = np.stack(obs)
+        B = len(obs)
+        legal = np.repeat(np.asarray(self.game.legal_actions(), dtype=np.float64)[None], B, axis=0)
+        values = None
+        if not getattr(cfg, 'mcts_target_value', True):
+            with torch.no_grad():
+                values = self.target_network.initial_inference(torch.as_tensor(obs, dtype=torch.float32))[2]
+            values = np.asarray(values.detach().cpu().numpy(), dtype=np.float64).reshape(B)
+        _, root_values, probs = self.mcts.search_batch(self.target_network, obs, legal, np.asarray(to_play), 0,
+                                                       action_encoder=self.game.action_encoder, seed=self.seed,
+                                                       tree_id0=tree_id0)
+        out, k = [], 0
+        for h in histories:
+            n = len(h)
+            p = [probs[k + i] for i in range(n)]
+            v = [float(x) for x in (root_values if values is None else values)[k:k + n]]
+            h.save_reanalysed_stats(p, v)
+            out.append((p, v))
+            k += n
+        return out

@@ -887,3 +887,65 @@ int orc_cartpole_step(double *s, int action, double *reward, float *obs)
     *reward = 1.0;
     return x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Training targets of one sampled position (GameHistory.make_target, games/game.py:185-253), on the
+ * game's own lists: rewards[T], to_plays[T], root_values[T] (the reanalysed ones when the game has
+ * them, :223), probs[T][A] (likewise, :245).  gamma_pow[k] = gamma**k as Python evaluates it
+ * (k <= td_steps).  Outputs are the float64 lists the reference returns, value/reward [U+1],
+ * policy [U+1][A].  Python's sum() starts from 0 and adds left to right. */
+void orc_make_target(int T, int A, const double *rewards, const int32_t *to_plays, const double *root_values,
+                     const double *probs, int t, int td_steps, double gamma, const double *gamma_pow,
+                     int unroll_steps, double *value_out, double *reward_out, double *policy_out)
+{
+    for (int step = t, j = 0; step <= t + unroll_steps; step++, j++) {
+        double value = 0.0;
+        if (gamma == 1.0) {                                    /* :214-220 */
+            for (int i = step; i < T; i++)
+                value += (to_plays[i] == to_plays[step]) ? rewards[i] : -rewards[i];
+        } else {                                               /* :221-235 */
+            int bootstrap_step = step + td_steps;
+            double bootstrap = 0.0;
+            if (bootstrap_step < T) {
+                bootstrap = (to_plays[bootstrap_step] == to_plays[step]) ? root_values[bootstrap_step]
+                                                                         : -root_values[bootstrap_step];
+                bootstrap *= gamma_pow[td_steps];
+            }
+            int k = 0;                                         /* enumerate(rewards[step+1 : bootstrap_step+1]) */
+            for (int i = step + 1; i < bootstrap_step + 1 && i < T; i++, k++) {
+                double r = (to_plays[step + k] == to_plays[step]) ? rewards[i] : -rewards[i];
+                value += r * gamma_pow[k];
+            }
+            value = value + bootstrap;
+        }
+        if (step < T) {                                        /* :241-247 */
+            value_out[j] = value;
+            reward_out[j] = rewards[step];
+            for (int a = 0; a < A; a++) policy_out[j * A + a] = probs[step * A + a];
+        } else {                                               /* :248-251 */
+            value_out[j] = 0.0;
+            reward_out[j] = 0.0;
+            for (int a = 0; a < A; a++) policy_out[j * A + a] = 1.0 / (double)A;
+        }
+    }
+}
+
+/* GameHistory.stack_n_observations for a non-empty history (games/game.py:143-160): newest first,
+ * optional action planes a / n_actions, zero planes when fewer than n observations exist.
+ * observations: [T][obs] float64; out: [n * (1 + stack_action)][obs]. */
+void orc_stack_observations(int T, int obs, const double *observations, const int32_t *actions, int t, int n,
+                            int n_actions, int stack_action, double *out)
+{
+    t = ((t % T) + T) % T;
+    int n_ = n < t + 1 ? n : t + 1, row = 0;
+    for (int step = t; step >= t - n_ + 1; step--) {
+        for (int i = 0; i < obs; i++) out[row * obs + i] = observations[step * obs + i];
+        row++;
+        if (stack_action) {
+            for (int i = 0; i < obs; i++) out[row * obs + i] = (double)actions[step] / (double)n_actions;
+            row++;
+        }
+    }
+    for (int r = 0; r < (n - n_) * (stack_action ? 2 : 1); r++, row++)
+        for (int i = 0; i < obs; i++) out[row * obs + i] = 0.0;
+}

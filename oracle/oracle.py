@@ -281,3 +281,33 @@ def search_batch_net(config, packed, root_logits, root_hidden, root_value, legal
                                _p(rv0), _p(lg), _p(tp), _p(di), C.c_double(frac), _p(gu), C.c_uint64(seed),
                                C.c_uint64(tree_id0), _p(rv), _p(val), _p(nv), _p(act), C.c_int(n_threads))
     return SimpleNamespace(root_visits=rv, root_value=val, node_visits=nv, action=act)
+
+
+def make_target(rewards, to_plays, root_values, probs, t, td_steps, gamma, unroll_steps):
+    """GameHistory.make_target on one game's lists -> (value[U+1], reward[U+1], policy[U+1][A]) float64."""
+    rewards = np.ascontiguousarray(rewards, np.float64)
+    tp = np.ascontiguousarray(to_plays, np.int32)
+    rv = np.ascontiguousarray(root_values, np.float64)
+    pr = np.ascontiguousarray(probs, np.float64)
+    T, A = pr.shape
+    gp = np.array([float(gamma) ** k for k in range(td_steps + 1)], np.float64)
+    v, r, p = np.zeros(unroll_steps + 1), np.zeros(unroll_steps + 1), np.zeros((unroll_steps + 1, A))
+    f = lib().orc_make_target
+    f.restype = None
+    f(C.c_int(T), C.c_int(A), _p(rewards), _p(tp), _p(rv), _p(pr), C.c_int(int(t)), C.c_int(int(td_steps)),
+      C.c_double(float(gamma)), _p(gp), C.c_int(int(unroll_steps)), _p(v), _p(r), _p(p))
+    return v, r, p
+
+
+def stack_observations(observations, actions, t, n, n_actions, stack_action):
+    """GameHistory.stack_n_observations on one non-empty game -> [n * (1 + stack_action), obs] float64."""
+    obs = np.ascontiguousarray(observations, np.float64)
+    T = obs.shape[0]
+    flat = obs.reshape(T, -1)
+    act = np.ascontiguousarray(actions, np.int32)
+    out = np.zeros((n * (2 if stack_action else 1), flat.shape[1]))
+    f = lib().orc_stack_observations
+    f.restype = None
+    f(C.c_int(T), C.c_int(flat.shape[1]), _p(flat), _p(act), C.c_int(int(t)), C.c_int(int(n)), C.c_int(int(n_actions)),
+      C.c_int(int(bool(stack_action))), _p(out))
+    return out

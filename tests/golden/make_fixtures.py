@@ -524,12 +524,162 @@ def gen_selfplay():
     print('selfplay_tictactoe.npz', gi, 'games')
 
 
+def _play_tictactoe(cfg, net, seed, tree_id):
+    """One self-play game with the reference's objects (the loop of self_play.py:77-115)."""
+    real_uniform = np.random.uniform
+    game = TicTacToe()
+    mcts = MCTS(cfg)
+    np.random.seed(seed)
+    observation = game.reset()
+    history = GameHistory(game.action_encoder, observation)
+    np.random.uniform = CounterUniform(seed, tree_id)
+    try:
+        while True:
+            to_play = game.to_play()
+            stacked = history.stack_n_observations(-1, cfg.n_stacked_observations, cfg.n_actions, cfg.stack_action)
+            action, root_value, probs = mcts.search(net, stacked, game.legal_actions(), game.action_encoder, to_play, 1.0)
+            next_observation, reward, terminated = game.step(action)
+            history.save(observation, action, reward, to_play, probs, root_value)
+            observation = next_observation
+            if terminated or len(history) > cfg.max_moves:
+                break
+    finally:
+        np.random.uniform = real_uniform
+    return history
+
+
+def gen_reanalyse():
+    """The body of Reanalyser.reanalyse (reanalyse.py:44-78; the actor itself needs ray) spelled out with
+    the reference's MCTS, TicTacToe and GameHistory: every position of a stored game is searched again
+    with a target network, from a fresh game's legal mask, and the game's targets are rebuilt."""
+    out, gi = {}, 0
+    real_uniform = np.random.uniform
+    for gumbel in (True, False):
+        for seed in (3, 4):
+            cfg = make_config(gumbel, 9, 20, 2, 1, alpha=0.2)
+            cfg.n_stacked_observations, cfg.stack_action, cfg.max_moves = 1, False, 9
+            play_net = hashnet.HashNetwork(hashnet.HashNetParams(9, 8, 3, 1, 1), obs_hash=True)
+            history = _play_tictactoe(cfg, play_net, seed, gi)
+            target_net = hashnet.HashNetwork(hashnet.HashNetParams(9, 8, 4, 1, 1), obs_hash=True)
+            fresh_game = TicTacToe()   # the reanalyser's own game object is never stepped
+            mcts = MCTS(cfg)
+            observations = [history.stack_n_observations(t, cfg.n_stacked_observations, cfg.n_actions, cfg.stack_action)
+                            for t in range(len(history))]
+            values = [target_net.initial_inference(torch.as_tensor(o, dtype=torch.float32).unsqueeze(0))[2].item()
+                      for o in observations]
+            np.random.seed(100 + seed)
+            probs, roots = [], []
+            try:
+                for t, o in enumerate(observations):
+                    np.random.uniform = CounterUniform(100 + seed, t)   # one noise key per position
+                    _, rv, ap = mcts.search(target_net, o, fresh_game.legal_actions(), fresh_game.action_encoder,
+                                            history.to_plays[t])
+                    probs.append(ap)
+                    roots.append(rv)
+            finally:
+                np.random.uniform = real_uniform
+            p = f'g{gi}_'
+            out[p + 'meta'] = np.array([gumbel, seed, gi, len(history)], dtype=np.int64)
+            out[p + 'observations'] = np.array(history.observations, dtype=np.float64)
+            out[p + 'actions'] = np.array(history.actions, dtype=np.int64)
+            out[p + 'rewards'] = np.array(history.rewards, dtype=np.float64)
+            out[p + 'to_plays'] = np.array(history.to_plays, dtype=np.int64)
+            out[p + 'probs'] = np.array(history.action_probabilities, dtype=np.float64)
+            out[p + 'root_values'] = np.array(history.root_values, dtype=np.float64)
+            out[p + 'stacked'] = np.array(observations, dtype=np.float64)
+            out[p + 'target_net_values'] = np.array(values, dtype=np.float64)
+            out[p + 're_probs'] = np.array(probs, dtype=np.float64)
+            out[p + 're_root_values'] = np.array(roots, dtype=np.float64)
+            out[p + 'next_random_sample'] = np.float64(np.random.random_sample())
+            history.save_reanalysed_stats(probs, roots)
+            vt, rt, pt = history.make_target(1, 5, cfg.gamma, 5, 9)
+            out[p + 'target_value'], out[p + 'target_reward'] = np.array(vt, dtype=np.float64), np.array(rt, dtype=np.float64)
+            out[p + 'target_policy'] = np.array(pt, dtype=np.float64)
+            gi += 1
+    out['n_games'] = np.int64(gi)
+    np.savez_compressed(os.path.join(HERE, 'reanalyse_tictactoe.npz'), **out)
+    print('reanalyse_tictactoe.npz', gi, 'games')
+
+
+def gen_targets():
+    """Training targets as ReplayBuffer.sample builds them (replay_buffer.py:59-105; the buffer itself is
+    a ray actor): reference GameHistory objects filled with synthetic trajectories, sampled positions,
+    `stack_n_observations`, absorbing-action padding and `make_target`, converted like `ftensor`."""
+    rng = np.random.default_rng(7)
+    out, ci = {}, 0
+    for players, gamma, A, td, unroll, reanalysed in ((1, 0.997, 2, 10, 5, False), (1, 0.997, 2, 3, 5, True),
+                                                       (2, 1, 9, 9, 5, False), (2, 0.9, 4, 4, 3, True),
+                                                       (2, 0.9, 4, 50, 6, False)):
+        one_hot = lambda a, A=A: np.eye(A)[a][None]  # noqa: E731
+        games = []
+        for g in range(6):
+            T = int(rng.integers(1, 14))
+            h = GameHistory(one_hot, np.zeros((1, 1, 4)))
+            for t in range(T):
+                pi = rng.dirichlet([0.5] * A)
+                h.save(rng.normal(size=(1, 1, 4)), int(rng.integers(A)), float(rng.integers(0, 3)) * 0.5,
+                       t % players, [float(x) for x in pi], float(rng.normal()))
+            if reanalysed:
+                h.save_reanalysed_stats([[float(x) for x in rng.dirichlet([0.5] * A)] for _ in range(T)],
+                                        [float(rng.normal()) for _ in range(T)])
+            games.append(h)
+        Bs = 16
+        np.random.seed(11 + ci)
+        sel = np.random.choice(range(len(games)), size=Bs)
+        batch, ts, absorbed = [[], [], [], [], []], [], []
+        for gidx in sel:
+            h = games[gidx]
+            t = np.random.randint(len(h))
+            ts.append(t)
+            obs = h.stack_n_observations(t, 1, A, False)
+            enc = h.encoded_actions[t:t + unroll + 1]
+            pad = []
+            if len(enc) < unroll + 1:
+                pad = list(np.random.choice(range(len(h.encoded_actions)), size=unroll + 1 - len(enc)))
+                enc = enc + [h.encoded_actions[i] for i in pad]
+            absorbed.append(pad + [-1] * (unroll + 1 - len(pad)))
+            vt, rt, pt = h.make_target(t, td, gamma, unroll, A)
+            for k, x in enumerate((obs, enc, vt, rt, pt)):
+                batch[k].append(x)
+        p = f'c{ci}_'
+        out[p + 'meta'] = np.array([players, A, td, unroll, int(reanalysed), len(games), Bs], dtype=np.int64)
+        out[p + 'gamma'] = np.float64(gamma)
+        out[p + 'gamma_pow'] = np.array([gamma ** k for k in range(td + 1)], dtype=np.float64)
+        for g, h in enumerate(games):
+            q = f'{p}g{g}_'
+            out[q + 'observations'] = np.array(h.observations, dtype=np.float64)
+            out[q + 'actions'] = np.array(h.actions, dtype=np.int64)
+            out[q + 'rewards'] = np.array(h.rewards, dtype=np.float64)
+            out[q + 'to_plays'] = np.array(h.to_plays, dtype=np.int64)
+            out[q + 'probs'] = np.array(h.action_probabilities, dtype=np.float64)
+            out[q + 'root_values'] = np.array(h.root_values, dtype=np.float64)
+            if reanalysed:
+                out[q + 're_probs'] = np.array(h.reanalysed_action_probabilities, dtype=np.float64)
+                out[q + 're_root_values'] = np.array(h.reanalysed_root_values, dtype=np.float64)
+        out[p + 'sel'] = np.asarray(sel, dtype=np.int64)
+        out[p + 't'] = np.asarray(ts, dtype=np.int64)
+        out[p + 'absorbed'] = np.asarray(absorbed, dtype=np.int64)
+        names = ('obs', 'actions', 'value', 'reward', 'policy')
+        for k, n in enumerate(names):   # ftensor(np.asarray(.)): float32 tensors
+            out[p + 'batch_' + n] = torch.as_tensor(np.asarray(batch[k]), dtype=torch.float32).numpy()
+        ci += 1
+    out['n_cases'] = np.int64(ci)
+    np.savez_compressed(os.path.join(HERE, 'targets.npz'), **out)
+    print('targets.npz', ci, 'cases')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     if len(sys.argv) > 1 and sys.argv[1] == 'selfplay':
         gen_selfplay()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'reanalyse':
+        gen_reanalyse()
+        gen_targets()
+        sys.exit(0)
     gen_selfplay()
+    gen_reanalyse()
+    gen_targets()
     gen_misc()
     gen_hash_fixtures()
     gen_stream_fixtures()
