@@ -163,6 +163,48 @@ def test_batched_search_vs_checker_at_scale(gumbel, A, S, players, gamma, H, B):
     eng.close()
 
 
+@pytest.mark.parametrize('gumbel,A,S,players,gamma,H,B', [
+    (False, 3, 1, 1, 0.9, 2, 1),       # a single simulation of a single tree
+    (True, 5, 7, 2, 1, 3, 3),
+    (False, 5, 12, 2, 1, 2, 5),
+    (True, 3, 33, 1, 0.99, 2, 7),
+    (False, 1, 6, 1, 0.99, 2, 4),      # one action: every tree is a chain
+    (True, 1, 6, 2, 1, 2, 4),
+    (False, 17, 9, 2, 1, 2, 65),       # ragged: 65 trees do not fill the last block
+])
+def test_edge_shapes_every_group_width(gumbel, A, S, players, gamma, H, B):
+    """Odd action counts, single trees / simulations and ragged batches, for every lane-group width the
+    library offers for the action count; whole trees compared with the CPU checker."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(100 + A * S)
+    cfg = make_config(gumbel, A, S, players, gamma)
+    hp = hashnet.HashNetParams(A, H, 4, 1, 1)
+    codes, legal = _batch_inputs(A, B, rng)
+    to_play = rng.integers(0, players, size=B).astype(np.int32)
+    gnoise = rng.gumbel(size=(B, A)) if gumbel else None
+    dirichlet = None if gumbel else rng.dirichlet([0.25] * A, size=B)
+    ref = orc.search_batch_hash(cfg, hp, H, codes, legal, to_play, dirichlet=dirichlet, frac=0.25, gumbel=gnoise,
+                                seed=3, tree_id0=5, n_threads=2)
+    rl = 2
+    while rl < A:
+        rl *= 2
+    for lanes in sorted({rl, max(rl, 16), 64}):
+        eng = _engine(cfg, H, B, seed=3, lanes_per_tree=lanes)
+        logits = np.stack([hashnet.logits_of(int(c), hp) for c in codes])
+        prior = eng.root_prepare(logits, legal, dirichlet, 0.25)
+        eng.reset(prior, [hashnet.value_of(int(c)) for c in codes],
+                  np.stack([hashnet.hidden_of(int(c), hp) for c in codes]), to_play, legal, gnoise, tree_id0=5)
+        eng.search_hash(4, 1, 1)
+        action, value, probs, _ = eng.to_act(0.0)
+        nv, _ = eng.stats()
+        assert np.array_equal(nv.cpu().numpy(), ref.node_visits), lanes
+        assert np.array_equal(value.cpu().numpy(), ref.root_value), lanes
+        assert np.array_equal(action.cpu().numpy(), ref.action), lanes
+        for b in range(B):
+            assert np.array_equal(eng.export_tree(b)['children_visits'][0], ref.root_visits[b]), (lanes, b)
+        eng.close()
+
+
 def test_root_prepare_vs_reference():
     for name in ('search_hash_puct.npz', 'search_hash_gumbel.npz'):
         for case in hash_cases(name)[::3]:
