@@ -83,7 +83,7 @@ def main():
 
     rank, world = mzdist.init()
     _, local_rank, _ = mzdist.env_rank_world()
-    torch.cuda.set_device(local_rank if world > 1 else 0)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if world > 1 else 0)
     dev = torch.device('cuda', torch.cuda.current_device())
 
     from muzero_amd.engine import SearchEngine
@@ -190,7 +190,7 @@ def main():
     torch.cuda.synchronize()
     mzdist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = mzdist.max_over_ranks(elapsed, dev if world > 1 else 'cpu')
+    elapsed = mzdist.max_over_ranks(elapsed, mzdist.reduce_device(dev))
 
     nv, _ = eng.stats()
     node_visits = int(nv.sum().item())
@@ -198,7 +198,7 @@ def main():
     alg = algorithmic_bytes(node_visits, B, S, A, H, gumbel)
     achieved = alg / (kern_ms * 1e-3) / 1e9
     sims = world * B * S * args.steps
-    nv_all = mzdist.sum_over_ranks(node_visits, dev if world > 1 else 'cpu')
+    nv_all = mzdist.sum_over_ranks(node_visits, mzdist.reduce_device(dev))
 
     traffic = None
     try:  # HBM bytes per launch from the PMC counters, measured offline with rocprofv3 (profiles/hbm_traffic.json)

@@ -24,8 +24,8 @@ def init(backend: Optional[str] = None) -> Tuple[int, int]:
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:  # MUZERO_AMD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with one GPU
+            backend = os.environ.get('MUZERO_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -37,6 +37,11 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     base, rem = divmod(int(n_total), int(world))
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def reduce_device(device):
+    """Where small reduction operands live: on the GPU for RCCL, on the host otherwise."""
+    return device if dist.is_initialized() and dist.get_backend() == 'nccl' else 'cpu'
 
 
 def barrier():
@@ -68,9 +73,11 @@ def gather_root_stats(action: torch.Tensor, root_value: torch.Tensor, probs: tor
         return action, root_value, probs
     b, A = probs.shape
     packed = torch.cat([action.to(torch.float64).reshape(b, 1), root_value.reshape(b, 1), probs], dim=1).contiguous()
+    if dist.get_backend() != 'nccl':
+        packed = packed.cpu()
     out = [torch.empty_like(packed) for _ in range(dist.get_world_size())]
     dist.all_gather(out, packed)
     if dist.get_rank() != dst:
         return None
-    full = torch.cat(out, dim=0)
+    full = torch.cat(out, dim=0).to(probs.device)
     return full[:, 0].to(torch.int32), full[:, 1].contiguous(), full[:, 2:].contiguous()
