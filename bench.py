@@ -54,7 +54,7 @@ WORKLOADS = {
     'cfg2': ('CartPole 256 envs x 50 sims PUCT, random-init MLP (BASELINE configs[1])', False, 2, 50, 1, 0.997, 256, 'mlp'),
     'cfg4s': ('CartPole 8192 envs x 50 sims PUCT search only, random-init MLP (configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'mlp'),
     'cfg4': ('CartPole self-play 8192 envs/GPU x 50 sims PUCT, fused env step, per-step gather of root stats to rank 0 (BASELINE configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'selfplay'),
-    'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), leaves evaluated on the matrix cores between the select and expand kernels (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
+    'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), whole search in one launch, leaves evaluated on the matrix cores (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
     'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
@@ -165,9 +165,7 @@ def main():
         if leaf == 'mlp':
             eng.search_net()
         elif leaf == 'mfma':
-            for _ in range(S):
-                eng.select(want_hidden=False)
-                eng.expand_backup_net()
+            eng.search_mfma()
         elif leaf == 'step':
             for _ in range(S):
                 parent, action, phid = eng.select()
@@ -217,7 +215,7 @@ def main():
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
         'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': 'k_select+k_net_step+k_expand_backup',
+                                'mfma': 'k_search_mfma',
                                 'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},

@@ -36,6 +36,7 @@ extern "C" {
 /* Built-in leaf evaluators for the fused search (mz_search_run). */
 #define MZ_NET_HASH 0        /* synthetic hash network (csrc/hashnet.h) */
 #define MZ_NET_DENSE 1       /* network lowered to a dense program (mz_set_network), weights resident in LDS */
+#define MZ_NET_MFMA 2        /* network in matrix-core layout (mz_set_network_mfma), n_actions <= 16 */
 
 /* The attributes MCTS reads from its config (mcts/mcts.py:27-30,68-69,90,112,162,181-227,236). */
 typedef struct mz_config {
@@ -144,8 +145,11 @@ int mz_set_network_mfma(mz_ctx *ctx, const int32_t *steps_h, int32_t n_steps, co
 
 /* Replaces network.recurrent_inference (mcts/mcts.py:240-243) + MCTS.expand + MCTS.backward
  * (mcts/mcts.py:116-164) for the pending selection of every tree: leaves are evaluated on the matrix
- * cores by the network given to mz_set_network_mfma, then expanded and backed up. */
-int mz_expand_backup_net(mz_ctx *ctx, void *stream);
+ * cores by the network given to mz_set_network_mfma, then expanded and backed up.  With select_next != 0
+ * (and simulations left) the same launch also runs the next MCTS.simulate (as mz_select without the
+ * optional outputs; noise as in mz_select), so a search is mz_select once, then n_simulations calls. */
+int mz_expand_backup_net(mz_ctx *ctx, int32_t select_next, const double *noise, int32_t noise_max_calls,
+                         void *stream);
 
 /* Uploads the representation and prediction programs behind network.initial_inference
  * (network.py:86-103).  io_h int32[8] = {obs offset in the representation scratch, raw hidden offset in it,

@@ -10,7 +10,6 @@
 
 #include "../../include/muzero_amd.h"
 #include "tree_ops.h"
-#include "net_mfma.h"
 #include "targets.h"
 
 using namespace mz;
@@ -166,6 +165,43 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_expand_backup(Dev d, int leaf, con
         for (int i = a; i < d.L.H; i += LANES) dst[i] = next_hidden[(long long)t * d.L.H + i];
     }
     if (a == 0) d.sel_depth[t] = -1;
+}
+
+// k_expand_backup for the pending selection followed at once by the next simulation's k_select: the
+// records the backup just wrote are still in the near caches when the descent re-reads them, and the
+// step loop needs one launch less per simulation.
+template <int LANES, int RL, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_backup_select(Dev d, int leaf, const float *logits,
+                                                             const double *value, const double *reward,
+                                                             const double *noise, int noise_max_calls)
+{
+    __shared__ __align__(16) double s_bk[MZ_BLOCK];
+    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
+    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
+    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
+    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
+    int t, a;
+    if (!group_ids<LANES>(d, &t, &a)) return;
+    bool on = a < d.L.A;
+    int parent = d.sel_parent[t], action = d.sel_action[t], ntp = d.sel_ntp[t], depth = d.sel_depth[t];
+    if (depth < 1 || depth > d.L.S || parent < 0 || parent >= leaf) {
+        if (a == 0) atomicExch(d.err, 1);
+        return;
+    }
+    const TreeMem m = tree_mem(d, t);
+    float lg = on ? logits[(long long)t * d.L.A + a] : 0.0f;
+    expand_backup<LANES, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t],
+                                 s_bk + (threadIdx.x / LANES) * LANES);
+    if (a == 0) d.visit_total[t] += depth + 1;
+    __threadfence_block();
+    const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
+    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
+    parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+    if (a == 0) {
+        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
+    }
 }
 
 // Whole search in one launch with the synthetic hash network as the leaf evaluator.
@@ -463,6 +499,8 @@ __device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, 
         }
     }
 }
+
+#include "net_mfma.h"  // matrix-core leaf evaluation; uses the epilogue helpers above
 
 // Root of a search evaluated on the device: initial_inference (network.py:86-103: representation,
 // normalisation, prediction, support_to_scalar) + root prior preparation + the root rows.
@@ -1230,11 +1268,37 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
     if (rc) return rc;
     if (c->B < 1) return fail(MZ_ERR_STATE, "mz_search_run: no tree (call mz_tree_reset first)");
     if (c->selected) return fail(MZ_ERR_STATE, "mz_search_run: a selection is pending");
-    if (net_kind != MZ_NET_HASH && net_kind != MZ_NET_DENSE) return fail(MZ_ERR_ARG, "mz_search_run: unsupported net_kind");
+    if (net_kind != MZ_NET_HASH && net_kind != MZ_NET_DENSE && net_kind != MZ_NET_MFMA)
+        return fail(MZ_ERR_ARG, "mz_search_run: unsupported net_kind");
     if ((rc = check_noise(c, noise, noise_max_calls, "mz_search_run"))) return rc;
     if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
     int n_sims = c->cfg.n_simulations - c->n_expanded;
     if (n_sims <= 0) return fail(MZ_ERR_STATE, "mz_search_run: all simulations already done");
+    if (net_kind == MZ_NET_MFMA) {
+        if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network_mfma first)");
+        if (c->rl > 16) return fail(MZ_ERR_ARG, "mz_search_run: the matrix-core search serves at most 16 actions; use the step API");
+        constexpr int tm = MZ_NET_TM;  // 16-tree tiles (two blocks per CU) measured no faster on the 3x3-board ResNet
+        const size_t lds = (size_t)c->mnet.stride * tm * 4;
+        if (lds + (size_t)tm * 16 * 8 > 160 * 1024)
+            return fail(MZ_ERR_ARG, "mz_search_run: activations of a tile do not fit in LDS beside the backup staging; use the step API");
+        hipError_t attr_err = hipSuccess;
+        auto launch = [&](auto kern) {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+            hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream,
+                               c->d, c->mnet, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
+        };
+        const bool g = c->cfg.gumbel != 0;
+        switch (c->rl) {
+        case 2: if (g) launch(k_search_mfma<tm, 2, true>); else launch(k_search_mfma<tm, 2, false>); break;
+        case 4: if (g) launch(k_search_mfma<tm, 4, true>); else launch(k_search_mfma<tm, 4, false>); break;
+        case 8: if (g) launch(k_search_mfma<tm, 8, true>); else launch(k_search_mfma<tm, 8, false>); break;
+        default: if (g) launch(k_search_mfma<tm, 16, true>); else launch(k_search_mfma<tm, 16, false>); break;
+        }
+        if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
+        c->n_expanded += n_sims;
+        return launch_status("mz_search_run");
+    }
     if (net_kind == MZ_NET_DENSE) {
         if (!c->net.meta) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network first)");
         size_t lds = ((size_t)c->net.n_data + c->net.n_meta + (size_t)(MZ_BLOCK / c->lanes) * c->net_scratch) * 4;
@@ -1638,7 +1702,8 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     return MZ_OK;
 }
 
-extern "C" int mz_expand_backup_net(mz_ctx *c, void *stream)
+extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double *noise, int32_t noise_max_calls,
+                                    void *stream)
 {
     int rc = check_ctx(c, "mz_expand_backup_net");
     if (rc) return rc;
@@ -1654,10 +1719,18 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, void *stream)
     hipLaunchKernelGGL(k_net_step, dim3((c->B + MZ_NET_TM - 1) / MZ_NET_TM), dim3(MZ_NET_NT), lds, (hipStream_t)stream, c->d,
                        c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
     if ((rc = launch_status("mz_expand_backup_net"))) return rc;
-    MZ_LAUNCH(c, k_expand_backup, false, c->B, 0, stream, c->d, leaf, (const float *)c->leaf_logits,
-              (const double *)c->leaf_value, (const double *)c->leaf_reward, (const float *)nullptr);
+    select_next = select_next && leaf < c->cfg.n_simulations;
+    if (select_next) {
+        if ((rc = check_noise(c, noise, noise_max_calls, "mz_expand_backup_net"))) return rc;
+        if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
+        MZ_LAUNCH(c, k_backup_select, false, c->B, 0, stream, c->d, leaf, (const float *)c->leaf_logits,
+                  (const double *)c->leaf_value, (const double *)c->leaf_reward, noise, (int)noise_max_calls);
+    } else {
+        MZ_LAUNCH(c, k_expand_backup, false, c->B, 0, stream, c->d, leaf, (const float *)c->leaf_logits,
+                  (const double *)c->leaf_value, (const double *)c->leaf_reward, (const float *)nullptr);
+    }
     c->n_expanded = leaf;
-    c->selected = 0;
+    c->selected = select_next ? 1 : 0;
     return launch_status("mz_expand_backup_net");
 }
 

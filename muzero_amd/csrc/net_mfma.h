@@ -40,11 +40,16 @@ __device__ __forceinline__ float apply_act(float v, int act)
 // consecutive floats of its tree's activations: one 16-byte LDS read) and the matching weight
 // W[col][same k] (one 16-byte global read of the pre-swizzled fragment).
 #define MZ_WPF 10  // weight fragments prefetched per job (k blocks of 16; larger K runs in rounds of this)
-__device__ __forceinline__ void mfma_tile(const MfmaNet &net, float *act, const int32_t *st, int ct, int lane)
+// HALVES = 2: both 16-row halves of the tile from one pass over the weights (two accumulator chains);
+// HALVES = 1: only half `half` (finer jobs, used to even out levels whose tile count does not divide
+// by the number of waves).
+template <int HALVES>
+__device__ __forceinline__ void mfma_tile(const MfmaNet &net, float *act, const int32_t *st, int ct, int half, int lane)
 {
     const int N = st[1], k16n = st[2], in_off = st[3], out_off = st[4], skip_off = st[5], actf = st[6];
     const float4 *wp = reinterpret_cast<const float4 *>(net.wfrag + st[7]) + (long long)ct * k16n * 64 + lane;
-    const float *a0 = act + (lane & 15) * net.stride + in_off + (lane >> 4) * 4;
+    const int row0 = HALVES == 2 ? 0 : half * 16;
+    const float *a0 = act + (row0 + (lane & 15)) * net.stride + in_off + (lane >> 4) * 4;
     const float *a1 = a0 + 16 * net.stride;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     for (int k0 = 0; k0 < k16n; k0 += MZ_WPF) {
@@ -56,15 +61,16 @@ __device__ __forceinline__ void mfma_tile(const MfmaNet &net, float *act, const 
         for (int i = 0; i < MZ_WPF; i++) {
             if (k0 + i < k16n) {
                 float4 x0 = *reinterpret_cast<const float4 *>(a0 + (k0 + i) * 16);
-                float4 x1 = *reinterpret_cast<const float4 *>(a1 + (k0 + i) * 16);
+                float4 x1 = {0, 0, 0, 0};
+                if constexpr (HALVES == 2) x1 = *reinterpret_cast<const float4 *>(a1 + (k0 + i) * 16);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, w[i].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w[i].x, acc1, 0, 0, 0);
+                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w[i].x, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, w[i].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w[i].y, acc1, 0, 0, 0);
+                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w[i].y, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, w[i].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w[i].z, acc1, 0, 0, 0);
+                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w[i].z, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, w[i].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w[i].w, acc1, 0, 0, 0);
+                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w[i].w, acc1, 0, 0, 0);
             }
         }
     }
@@ -74,14 +80,99 @@ __device__ __forceinline__ void mfma_tile(const MfmaNet &net, float *act, const 
         const float b = net.bias[st[8] + col];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            int r0 = (lane >> 4) * 4 + j;
+            int r0 = row0 + (lane >> 4) * 4 + j;
             float *o0 = act + r0 * net.stride, *o1 = o0 + 16 * net.stride;
-            float v0 = acc0[j] + b, v1 = acc1[j] + b;
-            if (skip_off >= 0) { v0 += o0[skip_off + col]; v1 += o1[skip_off + col]; }
+            float v0 = acc0[j] + b;
+            if (skip_off >= 0) v0 += o0[skip_off + col];
             o0[out_off + col] = apply_act(v0, actf);
-            o1[out_off + col] = apply_act(v1, actf);
+            if constexpr (HALVES == 2) {
+                float v1 = acc1[j] + b;
+                if (skip_off >= 0) v1 += o1[skip_off + col];
+                o1[out_off + col] = apply_act(v1, actf);
+            }
         }
     }
+}
+
+// Shared pieces of the two kernels below.  A block of MZ_NET_NT threads owns a tile of MZ_NET_TM trees;
+// tree i of the tile is also served by the 16-lane group i (threads 16 i .. 16 i + 15) for everything
+// that is per tree: staging its inputs, the epilogue, and (whole-search kernel) its tree operations.
+static_assert(MZ_NET_NT / MZ_NET_TM == 16, "one 16-lane group per tree of the tile");
+
+template <int TM>
+__device__ __forceinline__ void tile_zero(float *act, int stride, int tid)
+{
+    // Zero what the program reads but never writes: the padding behind every tensor (weights are zero
+    // there, but 0 * garbage must stay finite).  Cheapest is the whole tile, as 16-byte stores.
+    float4 z = {0, 0, 0, 0};
+    float4 *a4 = reinterpret_cast<float4 *>(act);
+    for (int i = tid; i < TM * stride / 4; i += TM * 16) a4[i] = z;
+}
+
+// inputs of one tree: hidden state of its selected PARENT and the encoded action (mcts/mcts.py:240-243)
+__device__ __forceinline__ void tile_stage_inputs(const MfmaNet &net, float *row, const float *ph, int action, int a)
+{
+    const int H = net.io[6], asz = net.io[8];
+    if ((H & 3) == 0) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(ph);
+        float4 *r4 = reinterpret_cast<float4 *>(row + net.io[0]);
+        for (int j = a; j < H / 4; j += 16) r4[j] = p4[j];
+    } else {
+        for (int j = a; j < H; j += 16) row[net.io[0] + j] = ph[j];
+    }
+    for (int j = a; j < asz; j += 16) row[net.io[1] + j] = j == action ? 1.0f : 0.0f;
+}
+
+// all levels of the program for a tile of TM (32 or 16) trees; ends with a workgroup barrier
+template <int TM>
+__device__ __forceinline__ void tile_run_levels(const MfmaNet &net, float *act, int wave, int lane)
+{
+    for (int l = 0; l < net.n_levels; l++) {
+        constexpr int NW = TM * 16 / 64;
+        const int first = net.level_start[l], n_tiles = net.level_start[l + 1] - first;
+        if constexpr (TM == 16) {  // one 16-row block per column tile
+            for (int ti = wave; ti < n_tiles; ti += NW) {
+                int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
+                mfma_tile<1>(net, act, net.steps + 12 * s, ct, 0, lane);
+            }
+            __syncthreads();
+            continue;
+        }
+        // whole tiles while they fill every wave; the remainder is dealt as half tiles
+        const int n_whole = n_tiles / NW * NW;
+        for (int ti = wave; ti < n_whole; ti += NW) {
+            int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
+            mfma_tile<2>(net, act, net.steps + 12 * s, ct, 0, lane);
+        }
+        for (int j = wave; j < 2 * (n_tiles - n_whole); j += NW) {
+            int ti = first + n_whole + (j >> 1);
+            int s = net.tiles[2 * ti], ct = net.tiles[2 * ti + 1];
+            mfma_tile<1>(net, act, net.steps + 12 * s, ct, j & 1, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// Epilogue of one tree by its 16-lane group: next hidden state (per-group min-max scaling,
+// utils/network_utils.py:132-158) into `hidden_dst`, value and reward (support_to_scalar,
+// utils/network_utils.py:75-96).  The policy logits stay in the tree's row at io[4].
+__device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *row, int a, float *hidden_dst,
+                                               double *value, double *reward)
+{
+    const int H = net.io[6], sup = net.io[9], ngroups = net.io[10];
+    const int per = H / ngroups;
+    if (ngroups >= 8) {  // many small groups (board planes): one lane per group
+        for (int g = a; g < ngroups; g += 16) {
+            const float *raw = row + net.io[2] + g * per;
+            float mn = raw[0], mx = raw[0];
+            for (int j = 1; j < per; j++) { float v = raw[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+            float den = (mx - mn) + 1e-5f;
+            for (int j = 0; j < per; j++) hidden_dst[g * per + j] = (raw[j] - mn) / den;
+        }
+    } else {
+        minmax_to<16>(row + net.io[2], H, ngroups, a, hidden_dst, nullptr);
+    }
+    support_to_scalar2<16>(row + net.io[5], row + net.io[3], sup, a, value, reward);
 }
 
 // recurrent_inference (network.py:105-126) for every tree's pending selection, then nothing else:
@@ -92,76 +183,72 @@ __global__ __launch_bounds__(MZ_NET_NT) void k_net_step(Dev d, MfmaNet net, int 
 {
     extern __shared__ __align__(16) float act[];  // [MZ_NET_TM][stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * MZ_NET_TM;
-    const int H = net.io[6], A = net.io[7], asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
-    // Zero what the program reads but never writes: the padding behind every tensor (weights are zero
-    // there, but 0 * garbage must stay finite).  Cheapest is the whole tile, as 16-byte stores.
-    {
-        float4 z = {0, 0, 0, 0};
-        float4 *a4 = reinterpret_cast<float4 *>(act);
-        for (int i = tid; i < MZ_NET_TM * net.stride / 4; i += MZ_NET_NT) a4[i] = z;
+    const int i = tid / 16, a = tid % 16, t = blockIdx.x * MZ_NET_TM + i;
+    const int H = net.io[6], A = net.io[7];
+    const bool live = t < d.B;
+    float *row = act + i * net.stride;
+    tile_zero<MZ_NET_TM>(act, net.stride, tid);
+    __syncthreads();
+    if (live) {
+        int parent = d.sel_parent[t], action = d.sel_action[t];
+        tile_stage_inputs(net, row, d.hidden + ((long long)t * d.L.N + parent) * H, action, a);
     }
     __syncthreads();
-    // inputs: hidden state of each tree's selected PARENT and the encoded action (mcts/mcts.py:240-243);
-    // 16 threads per tree so all 32 trees' dependent loads (parent index -> hidden row) are in flight together
-    {
-        constexpr int PT = MZ_NET_NT / MZ_NET_TM;
-        const int i = tid / PT, part = tid % PT, t = t0 + i;
-        if (t < d.B) {
-            int parent = d.sel_parent[t], action = d.sel_action[t];
-            const float *ph = d.hidden + ((long long)t * d.L.N + parent) * H;
-            float *row = act + i * net.stride;
-            if ((H & 3) == 0) {
-                const float4 *p4 = reinterpret_cast<const float4 *>(ph);
-                float4 *r4 = reinterpret_cast<float4 *>(row + net.io[0]);
-                for (int j = part; j < H / 4; j += PT) r4[j] = p4[j];
-            } else {
-                for (int j = part; j < H; j += PT) row[net.io[0] + j] = ph[j];
-            }
-            for (int j = part; j < asz; j += PT) row[net.io[1] + j] = j == action ? 1.0f : 0.0f;
-        }
-    }
+    tile_run_levels<MZ_NET_TM>(net, act, wave, lane);
+    if (!live) return;
+    double value, reward;
+    tile_epilogue(net, row, a, d.hidden + ((long long)t * d.L.N + leaf) * H, &value, &reward);
+    for (int j = a; j < A; j += 16) out_logits[(long long)t * A + j] = row[net.io[4] + j];
+    if (a == 0) { out_value[t] = value; out_reward[t] = reward; }
+}
+
+// The whole simulation loop in one launch with leaves evaluated on the matrix cores: per simulation
+// every group descends its tree and stages the leaf's inputs, the block runs the network for its
+// 32-tree tile, then every group finishes its tree (epilogue, expansion, backup).  Trees stay in
+// global memory; the tile's activations stay in LDS for the whole search.  RL <= 16.  TM = trees per
+// block: 16 lets two blocks share a CU, so one block's matrix work overlaps the other's tree work.
+template <int TM, int RL, bool GUMBEL>
+__global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int first_leaf, int n_sims,
+                                                            const double *noise, int noise_max_calls)
+{
+    extern __shared__ __align__(16) float act[];  // [TM][stride]
+    __shared__ __align__(16) double s_bk[TM * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = tid / 16, a = tid % 16, t = blockIdx.x * TM + i;
+    const int H = net.io[6], A = d.L.A;
+    const bool live = t < d.B, on = a < A;
+    float *row = act + i * net.stride;
+    double *bk = s_bk + i * 16;
+    tile_zero<TM>(act, net.stride, tid);
+    const int tt = live ? t : 0;  // groups past the end of the batch only keep the barriers company
+    const TreeMem m = tree_mem(d, tt);
+    float *hid = d.hidden + (long long)tt * d.L.N * H;
+    const double *nz = noise ? noise + (long long)tt * noise_max_calls * A : nullptr;
+    DescendCtx dc = descend_ctx<GUMBEL>(d, tt, a, on, nullptr, nullptr);
+    uint32_t calls = GUMBEL ? 0u : d.noise_calls[tt];
+    long long visited = 0;
     __syncthreads();
-    for (int l = 0; l < net.n_levels; l++) {
-        for (int ti = net.level_start[l] + wave; ti < net.level_start[l + 1]; ti += MZ_NET_NT / 64) {
-            int s = net.tiles[2 * ti], ct = net.tiles[2 * ti + 1];
-            mfma_tile(net, act, net.steps + 12 * s, ct, lane);
+    for (int s = 0; s < n_sims; s++) {
+        const int leaf = first_leaf + s;
+        int parent = 0, action = 0, ntp = 0, depth = 0;
+        if (live) {
+            parent = descend<16, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+            visited += depth + 1;
+            tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
         }
         __syncthreads();
+        tile_run_levels<TM>(net, act, wave, lane);
+        if (live) {
+            double value, reward;
+            tile_epilogue(net, row, a, hid + (long long)leaf * H, &value, &reward);
+            float lg = on ? row[net.io[4] + a] : 0.0f;
+            expand_backup<16, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
+            __threadfence_block();
+        }
     }
-    // next hidden state: per-group min-max scaling (utils/network_utils.py:132-158) into the leaf slot
-    const int per = H / ngroups;
-    for (int job = tid; job < MZ_NET_TM * ngroups; job += MZ_NET_NT) {
-        int i = job / ngroups, g = job % ngroups, t = t0 + i;
-        if (t >= d.B) continue;
-        const float *raw = act + i * net.stride + net.io[2] + g * per;
-        float mn = raw[0], mx = raw[0];
-        for (int j = 1; j < per; j++) { float v = raw[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-        float den = (mx - mn) + 1e-5f;
-        float *dst = d.hidden + ((long long)t * d.L.N + leaf) * H + g * per;
-        for (int j = 0; j < per; j++) dst[j] = (raw[j] - mn) / den;
-    }
-    for (int job = tid; job < MZ_NET_TM * A; job += MZ_NET_NT) {
-        int i = job / A, a = job % A, t = t0 + i;
-        if (t < d.B) out_logits[(long long)t * A + a] = act[i * net.stride + net.io[4] + a];
-    }
-    // value and reward: softmax over the support (float32), expectation in float64, inverse transform
-    for (int job = tid; job < MZ_NET_TM * 2; job += MZ_NET_NT) {
-        int i = job >> 1, which = job & 1, t = t0 + i;
-        if (t >= d.B) continue;
-        const float *lg = act + i * net.stride + (which ? net.io[3] : net.io[5]);
-        const int L = (sup - 1) / 2;
-        float mx = lg[0];
-        for (int j = 1; j < sup; j++) mx = lg[j] > mx ? lg[j] : mx;
-        float s = 0.0f;
-        for (int j = 0; j < sup; j++) s += expf(lg[j] - mx);
-        double x = 0.0;
-        for (int j = 0; j < sup; j++) x += (double)(expf(lg[j] - mx) / s) * (double)(j - L);
-        const double eps = 0.001;
-        double sg = x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
-        double tt = (sqrt(1 + 4 * eps * (fabs(x) + 1 + eps)) - 1) / (2 * eps);
-        double y = sg * (tt * tt - 1);
-        if (which) out_reward[t] = y; else out_value[t] = y;
+    if (live && a == 0) {
+        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        d.visit_total[t] += visited;
     }
 }
 

@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get('MUZERO_AMD_LIB') or os.path.join(_HERE, 'libmuzero_a
 _lib = None
 
 NOISE_COUNTER, NOISE_BUFFER, NOISE_NONE = 0, 1, 2
-NET_HASH, NET_DENSE = 0, 1
+NET_HASH, NET_DENSE, NET_MFMA = 0, 1, 2
 
 
 class EngineError(RuntimeError):
@@ -80,7 +80,7 @@ def lib():
         L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
         L.mz_set_network_mfma.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.c_int64, vp, i32, i32, vp]
-        L.mz_expand_backup_net.argtypes = [vp, vp]
+        L.mz_expand_backup_net.argtypes = [vp, i32, vp, i32, vp]
         L.mz_act_env_step.argtypes = [vp, C.POINTER(MzEnvState), f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mz_search_begin_net.argtypes = [vp, i32, vp, vp, vp, vp, f64, vp, u64, vp, vp, vp]
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
@@ -297,9 +297,14 @@ class SearchEngine:
                                          C.c_int64(pm.wfrag.size), vp(pm.bias), int(pm.bias.size), int(pm.stride),
                                          vp(io)))
 
-    def expand_backup_net(self):
-        """Leaf evaluation on the matrix cores + expansion + backup for the pending selection."""
-        _check(lib().mz_expand_backup_net(self._ctx, _stream()))
+    def expand_backup_net(self, select_next: bool = False, noise=None):
+        """Leaf evaluation on the matrix cores + expansion + backup for the pending selection; with
+        `select_next` the next simulation's selection runs in the same launch."""
+        nz, max_calls = None, 0
+        if noise is not None:
+            nz = self._dev(noise, torch.float64)
+            max_calls = nz.numel() // (self.B * self.A)
+        _check(lib().mz_expand_backup_net(self._ctx, C.c_int32(int(bool(select_next))), _ptr(nz), max_calls, _stream()))
 
     def search_net(self, noise=None):
         """All simulations in one launch, leaves evaluated by the uploaded network."""
@@ -308,6 +313,14 @@ class SearchEngine:
             nz = self._dev(noise, torch.float64)
             max_calls = nz.numel() // (self.B * self.A)
         _check(lib().mz_search_run(self._ctx, NET_DENSE, None, _ptr(nz), max_calls, _stream()))
+
+    def search_mfma(self, noise=None):
+        """All simulations in one launch, leaves evaluated on the matrix cores (set_network_mfma)."""
+        nz, max_calls = None, 0
+        if noise is not None:
+            nz = self._dev(noise, torch.float64)
+            max_calls = nz.numel() // (self.B * self.A)
+        _check(lib().mz_search_run(self._ctx, NET_MFMA, None, _ptr(nz), max_calls, _stream()))
 
     def to_act(self, temperature=0.0, u=None):
         B = self.B

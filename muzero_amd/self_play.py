@@ -143,7 +143,9 @@ class BatchedSelfPlay:
                 prior = eng.root_prepare(lg.reshape(self.B, e.A), e.legal, dirichlet, frac)
                 eng.reset(prior, val.reshape(self.B), hid.reshape(self.B, -1), e.to_play, e.legal, g,
                           tree_id0=self.tree_id0)
-                for _ in range(int(cfg.simulations)):
+                if self.mode == 'mfma' and e.A <= 16:
+                    eng.search_mfma(noise)   # the whole simulation loop in one launch
+                for _ in range(int(cfg.simulations) if not (self.mode == 'mfma' and e.A <= 16) else 0):
                     if self.mode == 'mfma':
                         eng.select(noise, want_hidden=False)
                         eng.expand_backup_net()

@@ -160,12 +160,25 @@ def test_mfma_leaf_evaluation_matches_torch_network(name, B):
     g = rng.gumbel(size=(B, A)) if gumbel else None
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     results = []
-    for mode in ('mfma', 'torch'):
+    for mode in ('mfma', 'mfma_fused', 'mfma_search', 'torch'):
         eng = SearchEngine(cfg, net.H, B, seed=2)
         eng.set_network_mfma(pm, io)
         prior = eng.root_prepare(logits, legal, di, 0.25)
         eng.reset(prior, value, hidden, tp, legal, g)
-        for sim in range(S):
+        if mode == 'mfma_fused':   # selection of the next simulation in the same launch as the backup
+            eng.select(want_hidden=False)
+            for sim in range(S):
+                eng.expand_backup_net(select_next=True)
+        if mode == 'mfma_search':  # the whole simulation loop in one launch (at most 16 actions)
+            if A <= 16:
+                eng.search_mfma()
+            else:
+                with pytest.raises(ValueError):
+                    eng.search_mfma()
+                eng.select(want_hidden=False)
+                for sim in range(S):
+                    eng.expand_backup_net(select_next=True)
+        for sim in range(S if mode in ('mfma', 'torch') else 0):
             parent, action, phid = eng.select()
             if mode == 'mfma':
                 if sim == 0:
@@ -185,5 +198,8 @@ def test_mfma_leaf_evaluation_matches_torch_network(name, B):
         a, v, p, _ = eng.to_act(0.0)
         results.append((a.cpu().numpy().copy(), v.cpu().numpy().copy()))
         eng.close()
-    assert (results[0][0] == results[1][0]).mean() >= 0.97
-    assert (np.abs(results[0][1] - results[1][1]) < 1e-5).mean() >= 0.97
+    for k in (1, 2):   # fewer launches, the very same search
+        np.testing.assert_array_equal(results[0][0], results[k][0])
+        np.testing.assert_array_equal(results[0][1], results[k][1])
+    assert (results[0][0] == results[3][0]).mean() >= 0.97
+    assert (np.abs(results[0][1] - results[3][1]) < 1e-5).mean() >= 0.97
