@@ -51,6 +51,7 @@ def tictactoe_net_config():
 
 WORKLOADS = {
     # name: (description, gumbel, A, S, players, gamma, B per GPU, leaf evaluator)
+    'cfg1': ('TicTacToe 1 tree x 25 sims PUCT, random-init ResNet, through the drop-in MCTS.search call with host inputs and outputs (BASELINE configs[0])', False, 9, 25, 2, 1, 1, 'dropin'),
     'cfg2': ('CartPole 256 envs x 50 sims PUCT, random-init MLP (BASELINE configs[1])', False, 2, 50, 1, 0.997, 256, 'mlp'),
     'cfg4s': ('CartPole 8192 envs x 50 sims PUCT search only, random-init MLP (configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'mlp'),
     'cfg4': ('CartPole self-play 8192 envs/GPU x 50 sims PUCT, fused env step, per-step gather of root stats to rank 0 (BASELINE configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'selfplay'),
@@ -97,7 +98,19 @@ def main():
     tree_id0 = rank * B
     packed = None
     sp = None
-    if leaf == 'selfplay':
+    if leaf == 'dropin':
+        sys.path.insert(0, os.path.join(REPO, 'muzero_amd'))
+        from mcts.mcts import MCTS  # the drop-in package, imported under the reference's name
+        cfg.dirichlet_alpha = 0.2
+        net = MuZeroNetwork(tictactoe_net_config(), seed=0)
+        H = net.H
+        searcher = MCTS(cfg)
+        obs0 = np.stack([np.zeros((3, 3)), np.zeros((3, 3)), np.full((3, 3), -1.0)])
+        enc = lambda a: np.eye(9)[a].reshape(3, 3)  # noqa: E731
+        np.random.seed(0)
+        searcher.search(net, obs0, np.ones(9), enc, 0, 1.0)
+        eng = searcher.last_engine
+    elif leaf == 'selfplay':
         from muzero_amd.self_play import BatchedSelfPlay
         cfg.max_moves = 500
         net = MuZeroNetwork(cartpole_net_config(), seed=0)
@@ -142,6 +155,13 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
+        if leaf == 'dropin':
+            if i is not None:
+                ev[i][0].record()
+            out = searcher.search(net, obs0, np.ones(9), enc, 0, 1.0)
+            if i is not None:
+                ev[i][1].record()
+            return out
         if leaf == 'selfplay':
             if i is not None:
                 ev[i][0].record()
@@ -215,7 +235,7 @@ def main():
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
         'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': 'k_search_mfma',
+                                'mfma': 'k_search_mfma', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},

@@ -71,6 +71,30 @@ class MCTS:
         return self._search(network, observations, legal_actions, to_play, temperature, action_encoder,
                             stream_noise=False, seed=seed, tree_id0=tree_id0)
 
+    @staticmethod
+    def _lowered_plan(network, A: int):
+        """How a lowered network (muzero_amd.network.MuZeroDenseNetwork) is evaluated inside the search
+        kernels: ('fused', PackedNetwork) when its weights fit in LDS, ('mfma', (PackedMfma, io)) for
+        larger ones with at most 16 actions, None otherwise (or for any other network object).
+        Packings are cached on the network and rebuilt when its weights change."""
+        if not (hasattr(network, 'dyn') and hasattr(network, 'pred') and hasattr(network, 'rep')):
+            return None
+        stamp = id(getattr(network, 'state_dict_cpu', None))
+        cached = getattr(network, '_mz_plan', None)
+        if cached is not None and cached[0] == stamp:
+            return cached[1]
+        from muzero_amd.packing import pack_network, pack_network_mfma
+        plan = None
+        packed = pack_network(network)
+        if max(p.weight_bytes() for p in (packed.recurrent, packed.represent, packed.predict)) <= 48 * 1024:
+            plan = ('fused', packed)
+        elif A <= 16:
+            pm, io = pack_network_mfma(network)
+            if pm.stride * 32 * 4 + 4096 <= 160 * 1024:
+                plan = ('mfma', (pm, io))
+        network._mz_plan = (stamp, plan)
+        return plan
+
     def _search(self, network, observations, legal_actions, to_play, temperature, action_encoder,
                 stream_noise, seed=0, tree_id0=0):
         cfg = self.config
@@ -78,50 +102,68 @@ class MCTS:
         obs = torch.as_tensor(np.asarray(observations), dtype=torch.float32)
         B = obs.shape[0]
         legal = np.asarray(legal_actions, dtype=np.float64).reshape(B, A)
-        with torch.no_grad():
-            logits, hidden, value = network.initial_inference(obs)
-        hidden_shape = tuple(hidden.shape[1:])
-        H = int(np.prod(hidden_shape))
         gumbel = bool(cfg.gumbel)
         noise_mode = _engine.NOISE_BUFFER if (stream_noise and not gumbel) else _engine.NOISE_COUNTER
+        plan = self._lowered_plan(network, A)
+        if plan is not None and plan[0] == 'fused':
+            H, logits, hidden, value = plan[1].H, None, None, None   # the root is evaluated on the device too
+        else:
+            with torch.no_grad():
+                logits, hidden, value = network.initial_inference(obs)
+            hidden_shape = tuple(hidden.shape[1:])
+            H = int(np.prod(hidden_shape))
         eng = self._engine_for(H, B, noise_mode, seed)
         dev = eng.device
+        if plan is not None and getattr(eng, '_plan_of', None) != (id(network), id(plan)):
+            if plan[0] == 'fused':
+                eng.set_network(plan[1])
+            else:
+                eng.set_network_mfma(*plan[1])
+            eng._plan_of = (id(network), id(plan))
         g = dirichlet = u_pre = None
         if gumbel:
             g = np.stack([np.random.gumbel(size=A) for _ in range(B)])
-            prior = eng.root_prepare(logits.reshape(B, A), legal)
+        elif stream_noise:
+            dirichlet = np.stack([np.random.dirichlet([cfg.dirichlet_alpha] * A) for _ in range(B)])
         else:
-            if stream_noise:
-                dirichlet = np.stack([np.random.dirichlet([cfg.dirichlet_alpha] * A) for _ in range(B)])
-            else:
-                # per tree: Dirichlet row, then the uniform of the final np.random.choice - the order in
-                # which B consecutive reference searches (tie-break uniforms aside) consume the stream
-                dirichlet, u_pre = np.empty((B, A)), np.empty(B)
-                for b in range(B):
-                    dirichlet[b] = np.random.dirichlet([cfg.dirichlet_alpha] * A)
-                    u_pre[b] = np.random.random_sample()
-            prior = eng.root_prepare(logits.reshape(B, A), legal, dirichlet, cfg.exploration_frac)
-        eng.reset(prior, value.reshape(B), hidden.reshape(B, H), np.asarray(to_play, dtype=np.int32).reshape(B),
-                  legal, g, tree_id0=tree_id0)
+            # per tree: Dirichlet row, then the uniform of the final np.random.choice - the order in
+            # which B consecutive reference searches (tie-break uniforms aside) consume the stream
+            dirichlet, u_pre = np.empty((B, A)), np.empty(B)
+            for b in range(B):
+                dirichlet[b] = np.random.dirichlet([cfg.dirichlet_alpha] * A)
+                u_pre[b] = np.random.random_sample()
+        frac = 0.0 if gumbel else cfg.exploration_frac
+        tp = np.asarray(to_play, dtype=np.int32).reshape(B)
+        if plan is not None and plan[0] == 'fused':
+            eng.begin_net(obs.reshape(B, -1), legal, tp, dirichlet, frac, g, tree_id0=tree_id0)
+        else:
+            prior = eng.root_prepare(logits.reshape(B, A), legal, dirichlet, frac)
+            eng.reset(prior, value.reshape(B), hidden.reshape(B, H), tp, legal, g, tree_id0=tree_id0)
         noise = rng_state = None
         if noise_mode == _engine.NOISE_BUFFER:
             # Pre-draw the longest possible run of per-selection rows (a chain tree makes
             # S(S+1)/2 calls), then rewind the stream to exactly the rows that were consumed.
             rng_state = np.random.get_state()
             noise = torch.as_tensor(np.random.uniform(size=(B, S * (S + 1) // 2, A)), device=dev)
-        net_dev = getattr(network, 'device', None)
-        for _ in range(S):
-            parent, action, phid = eng.select(noise)
-            with torch.no_grad():
-                if hasattr(network, 'recurrent_flat'):
-                    h_in = phid if net_dev == dev else phid.to(network.device)
-                    lg, nh, val, rew = network.recurrent_flat(h_in, network.encode_actions(action.to(h_in.device)))
-                else:
-                    acts = action.cpu().numpy()
-                    enc = torch.as_tensor(np.stack([np.asarray(action_encoder(int(a))) for a in acts]),
-                                          dtype=torch.float32)
-                    lg, nh, val, rew = network.recurrent_inference(phid.cpu().reshape(B, *hidden_shape), enc)
-            eng.expand_backup(lg.reshape(B, A), val.reshape(B), rew.reshape(B), nh.reshape(B, H))
+        if plan is not None:   # every simulation inside one launch
+            if plan[0] == 'fused':
+                eng.search_net(noise)
+            else:
+                eng.search_mfma(noise)
+        else:
+            net_dev = getattr(network, 'device', None)
+            for _ in range(S):
+                parent, action, phid = eng.select(noise)
+                with torch.no_grad():
+                    if hasattr(network, 'recurrent_flat'):
+                        h_in = phid if net_dev == dev else phid.to(network.device)
+                        lg, nh, val, rew = network.recurrent_flat(h_in, network.encode_actions(action.to(h_in.device)))
+                    else:
+                        acts = action.cpu().numpy()
+                        enc = torch.as_tensor(np.stack([np.asarray(action_encoder(int(a))) for a in acts]),
+                                              dtype=torch.float32)
+                        lg, nh, val, rew = network.recurrent_inference(phid.cpu().reshape(B, *hidden_shape), enc)
+                eng.expand_backup(lg.reshape(B, A), val.reshape(B), rew.reshape(B), nh.reshape(B, H))
         u = None
         if not gumbel:
             if rng_state is not None:
