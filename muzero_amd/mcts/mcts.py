@@ -39,6 +39,7 @@ class MCTS:
     def __init__(self, config) -> None:
         self.config = config
         self._engines = {}
+        self._lowered = {}
         self.last_engine: Optional[_engine.SearchEngine] = None
         self._last_meta = None
 
@@ -70,6 +71,30 @@ class MCTS:
         consecutive reference searches); the per-selection tie-break uniforms are counter-based (`muzero_amd/noise.py`) keyed by (seed, tree_id0 + b)."""
         return self._search(network, observations, legal_actions, to_play, temperature, action_encoder,
                             stream_noise=False, seed=seed, tree_id0=tree_id0)
+
+    def _auto_lower(self, network):
+        """A reference network object (an eval-mode `nn.Module` whose `state_dict()` has the layout of
+        network.py:133-186 / :405-479, described by this MCTS's config) is lowered once per weight
+        version so that its searches take the single-launch paths; anything else is returned as is and
+        evaluated between the select and expand kernels.  MUZERO_AMD_AUTOLOWER=0 turns this off."""
+        cfg = self.config
+        if hasattr(network, 'dyn') or os.environ.get('MUZERO_AMD_AUTOLOWER', '1') == '0':
+            return network
+        if not isinstance(network, torch.nn.Module) or network.training:
+            return network
+        if not all(hasattr(cfg, k) for k in ('network', 'observation_dim', 'support_limit', 'n_stacked_observations')):
+            return network
+        tensors = list(network.parameters()) + list(network.buffers())
+        stamp = tuple((id(x), x._version) for x in tensors)
+        cached = self._lowered.get(id(network))
+        if cached is None or cached[0] != stamp:
+            try:
+                from muzero_amd.network import MuZeroDenseNetwork
+                low = MuZeroDenseNetwork(cfg, network.state_dict())
+            except (KeyError, ValueError, AttributeError, RuntimeError, IndexError):
+                low = None  # not a layout this build lowers
+            cached = self._lowered[id(network)] = (stamp, low)
+        return cached[1] if cached[1] is not None else network
 
     @staticmethod
     def _lowered_plan(network, A: int):
@@ -103,6 +128,7 @@ class MCTS:
         B = obs.shape[0]
         legal = np.asarray(legal_actions, dtype=np.float64).reshape(B, A)
         gumbel = bool(cfg.gumbel)
+        network = self._auto_lower(network)
         noise_mode = _engine.NOISE_BUFFER if (stream_noise and not gumbel) else _engine.NOISE_COUNTER
         plan = self._lowered_plan(network, A)
         if plan is not None and plan[0] == 'fused':

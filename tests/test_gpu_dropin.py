@@ -169,3 +169,47 @@ def test_dense_network_batched_search_on_gpu(mcts_pkg):
         assert abs(float(values[0]) - float(z[p + 'search_value'])) < 1e-5
         np.testing.assert_allclose(probs[0], z[p + 'probs'], atol=1e-4)
         np.testing.assert_allclose(tree.node_values, z[p + 'node_values'], atol=1e-5)
+
+
+def test_reference_style_module_is_lowered_once_per_weight_version(mcts_pkg):
+    """An eval-mode nn.Module with the reference's state_dict layout takes the single-launch path: it is
+    lowered on first use, reused while its weights are untouched, lowered again after an in-place update."""
+    import torch
+    m = mcts_pkg[0]
+    from test_network_lowering import load_net, net_config
+
+    class Module(torch.nn.Module):          # only what MCTS looks at: parameters in the reference's layout
+        def __init__(self, sd):
+            super().__init__()
+            self.keys = list(sd)
+            self.store = torch.nn.ParameterList([torch.nn.Parameter(v.clone().float(), requires_grad=False)
+                                                 for v in sd.values()])
+
+        def state_dict(self, *a, **k):
+            return {key: p.data for key, p in zip(self.keys, self.store)}
+
+    z, net = load_net('mlp_cartpole')
+    ncfg = net_config('mlp_cartpole')
+    cfg = make_config(True, 2, 30, 1, 0.997)
+    for k, v in vars(ncfg).items():
+        setattr(cfg, k, v)
+    mod = Module(net.state_dict()).eval()
+    search = m.MCTS(cfg)
+    obs = np.random.default_rng(0).uniform(-0.05, 0.05, size=(4, 1, 1, 4))
+    np.random.seed(3)
+    a1, v1, p1 = search.search_batch(mod, obs, np.ones((4, 2)), np.zeros(4, np.int32))
+    low1 = search._lowered[id(mod)][1]
+    assert low1 is not None and hasattr(low1, 'dyn')
+    np.random.seed(3)
+    a2, v2, p2 = search.search_batch(net, obs, np.ones((4, 2)), np.zeros(4, np.int32))   # the lowered network itself
+    np.testing.assert_array_equal(v1, v2)
+    np.testing.assert_array_equal(p1, p2)
+    np.random.seed(3)
+    search.search_batch(mod, obs, np.ones((4, 2)), np.zeros(4, np.int32))
+    assert search._lowered[id(mod)][1] is low1                      # same weights: no new lowering
+    with torch.no_grad():
+        mod.store[0].mul_(1.5)
+    np.random.seed(3)
+    a3, v3, p3 = search.search_batch(mod, obs, np.ones((4, 2)), np.zeros(4, np.int32))
+    assert search._lowered[id(mod)][1] is not low1
+    assert not np.array_equal(v3, v1)
