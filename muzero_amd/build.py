@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuzero_amd.so')
 SOURCES = ['engine.hip']
-HEADERS = ['device_common.h', 'tree_ops.h', os.path.join('..', '..', 'include', 'muzero_amd.h')]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'muzero_amd.h')]
 # -ffp-contract=off: the tree arithmetic must round exactly like the reference's NumPy expressions.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17']
 

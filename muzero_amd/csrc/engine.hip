@@ -1,4 +1,5 @@
-// Kernels and C ABI of the batched search engine (gfx950).  See include/muzero_amd.h.
+// C ABI of the batched search engine (gfx950): contexts, argument checks and kernel launches.
+// See include/muzero_amd.h; the kernels live in the headers included below.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -9,947 +10,15 @@
 #include <vector>
 
 #include "../../include/muzero_amd.h"
-#include "tree_ops.h"
+#include "tree_kernels.h"  // device_common.h, tree_ops.h
+#include "dense_net.h"
+#include "net_mfma.h"      // matrix-core leaf evaluation; uses the epilogue helpers of dense_net.h
+#include "search_net.h"
+#include "env_step.h"
 #include "targets.h"
 
 using namespace mz;
 
-// ============================================================================ kernels
-
-#define MZ_BLOCK 256
-
-#define MZ_CT_LDS 512  // exploration-constant entries staged in LDS (covers n_simulations <= 510)
-
-// Copies the PUCT exploration-constant table into LDS (all threads of the block, before any exits).
-template <bool GUMBEL>
-__device__ __forceinline__ const double *stage_c_table(const Dev &d, double *lds_ct)
-{
-    if constexpr (GUMBEL) return nullptr;
-    if (d.L.S + 2 > MZ_CT_LDS) return nullptr;
-    for (int i = threadIdx.x; i < d.L.S + 2; i += blockDim.x) lds_ct[i] = d.c_table[i];
-    __syncthreads();
-    return lds_ct;
-}
-
-#define MZ_SQ_LDS (53 * 52)  // sqrt-table entries staged in LDS (covers n_simulations <= 51)
-
-template <bool GUMBEL>
-__device__ __forceinline__ const double *stage_sqrt_table(const Dev &d, double *lds_sq)
-{
-    if constexpr (GUMBEL) return nullptr;
-    const int n = (d.L.S + 2) * (d.L.S + 1);
-    if (!d.sqrt_table || n > MZ_SQ_LDS) return nullptr;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) lds_sq[i] = d.sqrt_table[i];
-    __syncthreads();
-    return lds_sq;
-}
-
-template <int LANES>
-__device__ __forceinline__ bool group_ids(const Dev &d, int *t, int *a)
-{
-    int gid = (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / LANES);
-    *t = gid;
-    *a = threadIdx.x % LANES;
-    return gid < d.B;
-}
-
-// Root rows + per-tree search state (mcts/mcts.py:93-96 on top of the lazily initialised storage).
-// `prior` is this lane's prepared root prior logit, `is_legal` this lane's legality.
-template <int LANES, bool GUMBEL>
-__device__ __forceinline__ void write_root(const Dev &d, int t, int a, bool on, double prior, double val,
-                                           int to_play, bool is_legal, double gumbel_a, int max_considered)
-{
-    RowView w = view(d, tree_mem(d, t), 0);
-    if (a == 0) {
-        NodeHdr h;
-        h.visits = 1; h.parent = -1; h.afp = -1; h.to_play = to_play; h.value = val; h.raw = val;
-        *w.hdr = h;
-        d.noise_calls[t] = 0;
-        d.visit_total[t] = 0;
-        d.sel_depth[t] = -1;
-    }
-    unsigned long long mask = __ballot(on && is_legal);
-    int sh = (int)((threadIdx.x % 64) / LANES) * LANES;  // this group's lanes inside the 64-bit ballot
-    if constexpr (LANES < 64) mask = (mask >> sh) & ((1ull << LANES) - 1ull);
-    if (on) {
-        w.cval[a] = 0.0; w.crew[a] = 0.0; w.cvis[a] = 0; w.cidx[a] = -1;
-        if (GUMBEL) {
-            reinterpret_cast<float *>(w.prior)[a] = (float)prior;
-            d.gumbel[(long long)t * d.L.A + a] = gumbel_a;
-        } else {
-            reinterpret_cast<double *>(w.prior)[a] = prior;
-        }
-    }
-    if (a == 0) {
-        d.legal[t] = mask;
-        int n_legal = __popcll(mask);
-        d.m_considered[t] = max_considered < n_legal ? max_considered : n_legal;
-    }
-}
-
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_reset(Dev d, const void *root_prior, const double *root_value,
-                                                     const float *root_hidden, const int32_t *root_to_play,
-                                                     const uint8_t *legal, const double *gumbel,
-                                                     int max_considered)
-{
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    const int A = d.L.A;
-    bool on = a < A;
-    long long k = (long long)t * A + a;
-    double prior = 0.0, g = 0.0;
-    if (on) {
-        prior = GUMBEL ? (double)reinterpret_cast<const float *>(root_prior)[k]
-                       : reinterpret_cast<const double *>(root_prior)[k];
-        if (GUMBEL) g = gumbel[k];
-    }
-    write_root<LANES, GUMBEL>(d, t, a, on, prior, root_value[t], root_to_play[t], on && legal[k] != 0, g,
-                              max_considered);
-    if (root_hidden) {
-        float *dst = d.hidden + (long long)t * d.L.N * d.L.H;
-        for (int i = a; i < d.L.H; i += LANES) dst[i] = root_hidden[(long long)t * d.L.H + i];
-    }
-}
-
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_select(Dev d, const double *noise, int noise_max_calls,
-                                                      float *out_parent_hidden, int32_t *out_parent,
-                                                      int32_t *out_action)
-{
-    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
-    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
-    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
-    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    bool on = a < d.L.A;
-    const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
-    int action, ntp, depth;
-    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
-    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-    int parent = descend<LANES, RL, GUMBEL>(d, dc, tree_mem(d, t), a, on, nz, noise_max_calls, calls, &action, &ntp,
-                                            &depth);
-    if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
-        d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
-        if (out_parent) out_parent[t] = parent;
-        if (out_action) out_action[t] = action;
-    }
-    if (out_parent_hidden) {
-        const float *src = d.hidden + ((long long)t * d.L.N + parent) * d.L.H;
-        for (int i = a; i < d.L.H; i += LANES) out_parent_hidden[(long long)t * d.L.H + i] = src[i];
-    }
-}
-
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_expand_backup(Dev d, int leaf, const float *logits,
-                                                             const double *value, const double *reward,
-                                                             const float *next_hidden)
-{
-    __shared__ __align__(16) double s_bk[MZ_BLOCK];
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    bool on = a < d.L.A;
-    int parent = d.sel_parent[t], action = d.sel_action[t], ntp = d.sel_ntp[t], depth = d.sel_depth[t];
-    if (depth < 1 || depth > d.L.S || parent < 0 || parent >= leaf) {  // select did not run for this leaf
-        if (a == 0) atomicExch(d.err, 1);
-        return;
-    }
-    float lg = on ? logits[(long long)t * d.L.A + a] : 0.0f;
-    expand_backup<LANES, GUMBEL>(d, tree_mem(d, t), a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t],
-                                 s_bk + (threadIdx.x / LANES) * LANES);
-    if (a == 0) d.visit_total[t] += depth + 1;
-    if (next_hidden) {
-        float *dst = d.hidden + ((long long)t * d.L.N + leaf) * d.L.H;
-        for (int i = a; i < d.L.H; i += LANES) dst[i] = next_hidden[(long long)t * d.L.H + i];
-    }
-    if (a == 0) d.sel_depth[t] = -1;
-}
-
-// k_expand_backup for the pending selection followed at once by the next simulation's k_select: the
-// records the backup just wrote are still in the near caches when the descent re-reads them, and the
-// step loop needs one launch less per simulation.
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_backup_select(Dev d, int leaf, const float *logits,
-                                                             const double *value, const double *reward,
-                                                             const double *noise, int noise_max_calls)
-{
-    __shared__ __align__(16) double s_bk[MZ_BLOCK];
-    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
-    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
-    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
-    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    bool on = a < d.L.A;
-    int parent = d.sel_parent[t], action = d.sel_action[t], ntp = d.sel_ntp[t], depth = d.sel_depth[t];
-    if (depth < 1 || depth > d.L.S || parent < 0 || parent >= leaf) {
-        if (a == 0) atomicExch(d.err, 1);
-        return;
-    }
-    const TreeMem m = tree_mem(d, t);
-    float lg = on ? logits[(long long)t * d.L.A + a] : 0.0f;
-    expand_backup<LANES, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value[t], reward[t],
-                                 s_bk + (threadIdx.x / LANES) * LANES);
-    if (a == 0) d.visit_total[t] += depth + 1;
-    __threadfence_block();
-    const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
-    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
-    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-    parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
-    if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
-        d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
-    }
-}
-
-// Whole search in one launch with the synthetic hash network as the leaf evaluator.
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int first_leaf, int n_sims,
-                                                           const double *noise, int noise_max_calls)
-{
-    __shared__ __align__(16) double s_bk[MZ_BLOCK];
-    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
-    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
-    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
-    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    const int A = d.L.A, H = d.L.H;
-    bool on = a < A;
-    const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
-    float *hid = d.hidden + (long long)t * d.L.N * H;
-    double *bk = s_bk + (threadIdx.x / LANES) * LANES;
-    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
-    const TreeMem m = tree_mem(d, t);
-    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-    long long visited = 0;
-    for (int s = 0; s < n_sims; s++) {
-        int leaf = first_leaf + s;
-        int action, ntp, depth;
-        int parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
-        visited += depth + 1;
-        const float *ph = hid + (long long)parent * H;
-        uint32_t pcode = (uint32_t)ph[0] | ((uint32_t)ph[1] << 16);
-        uint32_t ccode = hash2(pcode, 300 + action);
-        uint32_t src = hn.parent_predicts ? pcode : ccode;
-        float lg = on ? hash_logit(src, a, hn.logit_shift) : 0.0f;
-        expand_backup<LANES, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, hash_value(src),
-                                     hash_reward(ccode, hn.reward_on), bk);
-        float *dst = hid + (long long)leaf * H;
-        for (int i = a; i < H; i += LANES) dst[i] = hash_hidden(ccode, i);
-        __threadfence_block();  // this group's stores are read by its other lanes in the next descent
-    }
-    if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
-        d.visit_total[t] += visited;
-    }
-}
-
-
-// ---------------------------------------------------------------------------- fused network search
-// Leaf evaluation by a lowered network ("dense program", layout in muzero_amd/packing.py) whose
-// weights fit in LDS: the block stages weights + tables once, every lane group owns an activation
-// scratch in LDS, and a level's output rows are spread over the group's lanes.
-struct NetDev {
-    const int32_t *meta;
-    const float *data;
-    int n_meta, n_data;
-    int io[12];  // in_hidden, in_action, out_next, out_reward, out_policy, out_value, H, A, action_size, support, norm_groups, obs
-};
-
-// utils/network_utils.py:75-96 over `n` logits held in LDS: float32 softmax, expectation over the
-// integer support in float64, inverse of h(x) = sign(x)(sqrt(|x|+1)-1) + 0.001x.  Two vectors
-// (value and reward logits) go through together so their dependent chains overlap.
-__device__ __forceinline__ double inv_value_transform(double x)
-{
-    const double eps = 0.001;
-    double sg = x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
-    double t = (sqrt(1 + 4 * eps * (fabs(x) + 1 + eps)) - 1) / (2 * eps);
-    return sg * (t * t - 1);
-}
-
-template <int LANES>
-__device__ __forceinline__ void support_to_scalar2(const float *lgA, const float *lgB, int n, int a,
-                                                   double *outA, double *outB)
-{
-    const int L = (n - 1) / 2;
-    if constexpr (LANES == 64) {
-        if (n <= 32) {  // one vector per half of the wave: a single set of half-wave reductions serves both
-            const bool up = a >= 32;
-            const int i = a & 31;
-            const float ninf = -__builtin_huge_valf();
-            float v = i < n ? (up ? lgB : lgA)[i] : ninf;
-            float m = half_reduce(v, ninf, up, [](float x, float y) { return y > x ? y : x; });
-            float e = i < n ? expf(v - m) : 0.0f;
-            float sum = half_reduce(e, 0.0f, up, [](float x, float y) { return x + y; });
-            double x = i < n ? (double)(e / sum) * (double)(i - L) : 0.0;
-            x = half_reduce(x, 0.0, up, [](double p, double q) { return p + q; });
-            double y = inv_value_transform(x);
-            *outA = wave_lane(y, 0);
-            *outB = wave_lane(y, 32);
-            return;
-        }
-    }
-    int W = 2;
-    while (W < n && W < LANES) W <<= 1;  // lanes that hold elements
-    const bool single = n <= LANES;      // one element per lane: keep it in registers
-    float mA = -__builtin_huge_valf(), mB = -__builtin_huge_valf();
-    float vA = 0, vB = 0;
-    if (single) {
-        if (a < n) { vA = lgA[a]; vB = lgB[a]; mA = vA; mB = vB; }
-    } else {
-        for (int i = a; i < n; i += LANES) { mA = lgA[i] > mA ? lgA[i] : mA; mB = lgB[i] > mB ? lgB[i] : mB; }
-    }
-    auto fmaxl = [](float x, float y) { return y > x ? y : x; };
-    auto faddl = [](float x, float y) { return x + y; };
-    auto daddl = [](double x, double y) { return x + y; };
-    if constexpr (LANES == 64) { mA = wave_reduce(mA, -__builtin_huge_valf(), fmaxl); mB = wave_reduce(mB, -__builtin_huge_valf(), fmaxl); }
-    else { mA = gmaxf<LANES>(mA, W); mB = gmaxf<LANES>(mB, W); }
-    float sA = 0.0f, sB = 0.0f, eA = 0.0f, eB = 0.0f;
-    if (single) {
-        if (a < n) { eA = expf(vA - mA); eB = expf(vB - mB); }
-        sA = eA; sB = eB;
-    } else {
-        for (int i = a; i < n; i += LANES) { sA += expf(lgA[i] - mA); sB += expf(lgB[i] - mB); }
-    }
-    if constexpr (LANES == 64) { sA = wave_reduce(sA, 0.0f, faddl); sB = wave_reduce(sB, 0.0f, faddl); }
-    else { sA = gsumf_any<LANES>(sA, W); sB = gsumf_any<LANES>(sB, W); }
-    double xA = 0.0, xB = 0.0;
-    if (single) {
-        if (a < n) { xA = (double)(eA / sA) * (double)(a - L); xB = (double)(eB / sB) * (double)(a - L); }
-    } else {
-        for (int i = a; i < n; i += LANES) {
-            xA += (double)(expf(lgA[i] - mA) / sA) * (double)(i - L);
-            xB += (double)(expf(lgB[i] - mB) / sB) * (double)(i - L);
-        }
-    }
-    if constexpr (LANES == 64) { xA = wave_reduce(xA, 0.0, daddl); xB = wave_reduce(xB, 0.0, daddl); }
-    else { xA = gsumd_any<LANES>(xA, W); xB = gsumd_any<LANES>(xB, W); }
-    if constexpr (LANES == 64) {
-        double y = inv_value_transform(a == 1 ? xB : xA);
-        *outA = wave_lane(y, 0);
-        *outB = wave_lane(y, 1);
-    } else if constexpr (LANES >= 2) {
-        // one pass of the (long, float64) inverse transform: lane 0 takes the first vector, lane 1 the second
-        double y = inv_value_transform(a == 1 ? xB : xA);
-        *outA = __shfl(y, 0, LANES);
-        *outB = __shfl(y, 1, LANES);
-    } else {
-        *outA = inv_value_transform(xA);
-        *outB = inv_value_transform(xB);
-    }
-}
-
-template <int LANES>
-__device__ __forceinline__ double support_to_scalar(const float *lg, int n, int a)
-{
-    double x, y;
-    support_to_scalar2<LANES>(lg, lg, n, a, &x, &y);
-    return x;
-}
-
-__device__ __forceinline__ void lds_fence()
-{
-    // LDS operations of one wave complete in order; this only stops the compiler from moving them.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// One evaluation of a dense program by a lane group: rows of a level are spread over the lanes.
-template <int LANES>
-__device__ __forceinline__ void dense_run(const int32_t *meta, const float *w, float *sc, int a)
-{
-    const int n_levels = meta[0];
-    const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
-    const float *bias = w + meta[4];
-    for (int l = 0; l < n_levels; l++) {
-        const int n_rows = lv[4 * l], kmax = lv[4 * l + 1], row0 = lv[4 * l + 3];
-        const float *WT = w + lv[4 * l + 2];
-        const float4 *W4 = reinterpret_cast<const float4 *>(WT);
-        const int k4n = kmax >> 2;
-        for (int r = a; r < n_rows; r += LANES) {
-            const int4 ds = *reinterpret_cast<const int4 *>(rows + 4 * (row0 + r));
-            const float4 *x4 = reinterpret_cast<const float4 *>(sc + ds.x);
-            float acc = bias[row0 + r];
-#pragma unroll 4
-            for (int k = 0; k < k4n; k++) {
-                float4 wv = W4[k * n_rows + r], xv = x4[k];
-                acc = fmaf(wv.x, xv.x, acc);
-                acc = fmaf(wv.y, xv.y, acc);
-                acc = fmaf(wv.z, xv.z, acc);
-                acc = fmaf(wv.w, xv.w, acc);
-            }
-            if (ds.w >= 0) acc += sc[ds.w];
-            if (ds.z == 1) acc = acc > 0.0f ? acc : 0.0f;
-            else if (ds.z == 2) acc = acc > 0.0f ? acc : expm1f(acc);
-            sc[ds.y] = acc;
-        }
-        lds_fence();
-    }
-}
-
-// A program of at most MAXL levels whose levels have at most one row per lane and at most 4 * MAXK4
-// inputs: each lane keeps its row's descriptor, bias and weights in registers across evaluations, so an
-// evaluation only reads the inputs from LDS.  Same operation order as dense_run.
-template <int MAXL, int MAXK4>
-struct DenseRegs {
-    int4 ds[MAXL];
-    float bias[MAXL];
-    float4 w[MAXL][MAXK4];
-    int k4n[MAXL];
-    int n_levels;
-};
-
-template <int LANES, int MAXL, int MAXK4>
-__device__ __forceinline__ bool dense_cacheable(const int32_t *meta)
-{
-    if (meta[0] > MAXL) return false;
-    const int32_t *lv = meta + meta[5];
-    for (int l = 0; l < meta[0]; l++)
-        if (lv[4 * l] > LANES || lv[4 * l + 1] > 4 * MAXK4) return false;
-    return true;
-}
-
-template <int LANES, int MAXL, int MAXK4>
-__device__ __forceinline__ void dense_cache_load(const int32_t *meta, const float *w, int a, DenseRegs<MAXL, MAXK4> &c)
-{
-    const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
-    const float *bias = w + meta[4];
-    c.n_levels = meta[0];
-#pragma unroll
-    for (int l = 0; l < MAXL; l++) {
-        c.ds[l] = make_int4(0, -1, 0, -1);
-        c.bias[l] = 0.0f;
-        c.k4n[l] = 0;
-#pragma unroll
-        for (int k = 0; k < MAXK4; k++) c.w[l][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (l < c.n_levels) {
-            const int n_rows = lv[4 * l], row0 = lv[4 * l + 3];
-            const float4 *W4 = reinterpret_cast<const float4 *>(w + lv[4 * l + 2]);
-            c.k4n[l] = lv[4 * l + 1] >> 2;
-            if (a < n_rows) {
-                c.ds[l] = *reinterpret_cast<const int4 *>(rows + 4 * (row0 + a));
-                c.bias[l] = bias[row0 + a];
-#pragma unroll
-                for (int k = 0; k < MAXK4; k++)
-                    if (k < c.k4n[l]) c.w[l][k] = W4[k * n_rows + a];
-            }
-        }
-    }
-}
-
-template <int MAXL, int MAXK4>
-__device__ __forceinline__ void dense_run_cached(const DenseRegs<MAXL, MAXK4> &c, float *sc)
-{
-#pragma unroll
-    for (int l = 0; l < MAXL; l++) {
-        if (l < c.n_levels) {
-            const int4 ds = c.ds[l];
-            if (ds.y >= 0) {
-                const float4 *x4 = reinterpret_cast<const float4 *>(sc + ds.x);
-                float acc = c.bias[l];
-#pragma unroll
-                for (int k = 0; k < MAXK4; k++) {
-                    if (k < c.k4n[l]) {
-                        float4 wv = c.w[l][k], xv = x4[k];
-                        acc = fmaf(wv.x, xv.x, acc);
-                        acc = fmaf(wv.y, xv.y, acc);
-                        acc = fmaf(wv.z, xv.z, acc);
-                        acc = fmaf(wv.w, xv.w, acc);
-                    }
-                }
-                if (ds.w >= 0) acc += sc[ds.w];
-                if (ds.z == 1) acc = acc > 0.0f ? acc : 0.0f;
-                else if (ds.z == 2) acc = acc > 0.0f ? acc : expm1f(acc);
-                sc[ds.y] = acc;
-            }
-            lds_fence();
-        }
-    }
-}
-
-// utils/network_utils.py:132-158: per-group min-max scaling of `raw` (LDS) into `dst` (and `dst2` if given).
-template <int LANES>
-__device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, int a, float *dst, float *dst2)
-{
-    const int per = H / ngroups;
-    for (int g = 0; g < ngroups; g++) {
-        const float *r = raw + g * per;
-        float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
-        for (int i = a; i < per; i += LANES) { float v = r[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-        int W = 2;
-        while (W < per && W < LANES) W <<= 1;
-        if constexpr (LANES == 64) {
-            if (W <= 16) {  // the values sit in one row of 16 lanes
-                mn = gminf<16>(mn, W); mx = gmaxf<16>(mx, W);
-            } else {
-                mn = wave_reduce(mn, __builtin_huge_valf(), [](float x, float y) { return y < x ? y : x; });
-                mx = wave_reduce(mx, -__builtin_huge_valf(), [](float x, float y) { return y > x ? y : x; });
-            }
-        } else {
-            mn = gminf<LANES>(mn, W); mx = gmaxf<LANES>(mx, W);
-        }
-        float den = (mx - mn) + 1e-5f;
-        for (int i = a; i < per; i += LANES) {
-            float v = (r[i] - mn) / den;
-            dst[g * per + i] = v;
-            if (dst2) dst2[g * per + i] = v;
-        }
-    }
-}
-
-#include "net_mfma.h"  // matrix-core leaf evaluation; uses the epilogue helpers above
-
-// Root of a search evaluated on the device: initial_inference (network.py:86-103: representation,
-// normalisation, prediction, support_to_scalar) + root prior preparation + the root rows.
-struct RootNetDev {
-    const int32_t *rep_meta, *pred_meta;
-    const float *rep_data, *pred_data;
-    int rep_n_meta, rep_n_data, pred_n_meta, pred_n_data;
-    int rep_scratch, pred_scratch;
-    int obs_off, raw_off, hid_off, pol_off, val_off, obs_size, support, ngroups;
-};
-
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_begin_net(Dev d, RootNetDev rn, const float *obs,
-                                                         const uint8_t *legal, const int32_t *to_play,
-                                                         const double *dirichlet, double frac,
-                                                         const double *gumbel, int max_considered,
-                                                         float *out_logits, double *out_value)
-{
-    extern __shared__ __align__(16) float lds[];
-    float *rw = lds;
-    int32_t *rm = reinterpret_cast<int32_t *>(rw + rn.rep_n_data);
-    float *pw = reinterpret_cast<float *>(rm + rn.rep_n_meta);
-    int32_t *pm = reinterpret_cast<int32_t *>(pw + rn.pred_n_data);
-    float *scratch0 = reinterpret_cast<float *>(pm + rn.pred_n_meta);
-    for (int i = threadIdx.x; i < rn.rep_n_data; i += MZ_BLOCK) rw[i] = rn.rep_data[i];
-    for (int i = threadIdx.x; i < rn.rep_n_meta; i += MZ_BLOCK) rm[i] = rn.rep_meta[i];
-    for (int i = threadIdx.x; i < rn.pred_n_data; i += MZ_BLOCK) pw[i] = rn.pred_data[i];
-    for (int i = threadIdx.x; i < rn.pred_n_meta; i += MZ_BLOCK) pm[i] = rn.pred_meta[i];
-    const int per_group = rn.rep_scratch + rn.pred_scratch;
-    float *sr = scratch0 + (size_t)(threadIdx.x / LANES) * per_group, *sp = sr + rn.rep_scratch;
-    for (int i = threadIdx.x % LANES; i < per_group; i += LANES) sr[i] = 0.0f;
-    __syncthreads();
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    const int A = d.L.A, H = d.L.H;
-    bool on = a < A;
-    for (int i = a; i < rn.obs_size; i += LANES) sr[rn.obs_off + i] = obs[(long long)t * rn.obs_size + i];
-    lds_fence();
-    dense_run<LANES>(rm, rw, sr, a);
-    minmax_to<LANES>(sr + rn.raw_off, H, rn.ngroups, a, d.hidden + (long long)t * d.L.N * H, sp + rn.hid_off);
-    lds_fence();
-    dense_run<LANES>(pm, pw, sp, a);
-    double value = support_to_scalar<LANES>(sp + rn.val_off, rn.support, a);
-    float lg = on ? sp[rn.pol_off + a] : 0.0f;
-    long long k = (long long)t * A + a;
-    bool lgl = on && legal[k] != 0;
-    double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
-    double pr = root_prior<RL, GUMBEL>(lg, on, lgl, di, frac, a, A, true);
-    write_root<LANES, GUMBEL>(d, t, a, on, pr, value, to_play[t], lgl, (GUMBEL && on) ? gumbel[k] : 0.0,
-                              max_considered);
-    if (out_logits && on) out_logits[k] = lg;
-    if (out_value && a == 0) out_value[t] = value;
-}
-
-// TREE_LDS: each group's node records, hidden states and path live in LDS for the whole search (staged in
-// at the start, written back at the end); `tree_lds_bytes` is the per-group size of that region.
-template <int LANES, int RL, bool GUMBEL, bool TREE_LDS>
-__global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int first_leaf, int n_sims,
-                                                          const double *noise, int noise_max_calls,
-                                                          int scratch_floats, int tree_lds_bytes)
-{
-    extern __shared__ __align__(16) float lds[];
-    float *w = lds;                                                  // [n_data]
-    int32_t *meta = reinterpret_cast<int32_t *>(lds + net.n_data);   // [n_meta]
-    float *scratch0 = lds + net.n_data + net.n_meta;
-    for (int i = threadIdx.x; i < net.n_data; i += MZ_BLOCK) w[i] = net.data[i];
-    for (int i = threadIdx.x; i < net.n_meta; i += MZ_BLOCK) meta[i] = net.meta[i];
-    float *sc = scratch0 + (size_t)(threadIdx.x / LANES) * scratch_floats;
-    for (int i = threadIdx.x % LANES; i < scratch_floats; i += LANES) sc[i] = 0.0f;
-    __shared__ __align__(16) double s_bk[MZ_BLOCK];
-    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
-    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
-    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
-    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
-    __syncthreads();
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    const int A = d.L.A, H = d.L.H;
-    bool on = a < A;
-    const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
-    float *hid = d.hidden + (long long)t * d.L.N * H;
-    float *const hid_global = hid;
-    TreeMem m = tree_mem(d, t);
-    const TreeMem m_global = m;
-    if constexpr (TREE_LDS) {
-        // region after the groups' activation scratch, 16-byte aligned: records | hidden | path
-        size_t base = ((size_t)(net.n_data + net.n_meta) + (size_t)(MZ_BLOCK / LANES) * scratch_floats) * 4;
-        base = (base + 15) & ~(size_t)15;
-        char *tl = reinterpret_cast<char *>(lds) + base + (size_t)(threadIdx.x / LANES) * tree_lds_bytes;
-        const int rec_bytes = (d.L.N * d.L.rec + 15) & ~15, hid_bytes = (d.L.N * H * 4 + 15) & ~15;
-        m.nodes = tl;
-        hid = reinterpret_cast<float *>(tl + rec_bytes);
-        m.path = reinterpret_cast<int32_t *>(tl + rec_bytes + hid_bytes);
-        m.depth = m.path + ((d.L.S + 3) & ~3);
-        const int32_t *src = reinterpret_cast<const int32_t *>(m_global.nodes);
-        int32_t *dst = reinterpret_cast<int32_t *>(m.nodes);
-        for (int i = a; i < first_leaf * (d.L.rec / 4); i += LANES) dst[i] = src[i];
-        for (int i = a; i < first_leaf * H; i += LANES) hid[i] = hid_global[i];
-        lds_fence();
-        if (a == 0) {  // parents precede their children, so one forward sweep gives every depth
-            m.depth[0] = 0;
-            for (int n = 1; n < first_leaf; n++) m.depth[n] = m.depth[view(d, m, n).hdr->parent] + 1;
-        }
-        lds_fence();
-    }
-    constexpr bool WIDE = TREE_LDS && LANES == 64 && RL == 2;
-    const bool wide = WIDE && d.L.N <= 2 * (64 / RL);
-    double *bk = s_bk + (threadIdx.x / LANES) * LANES;
-    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
-    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-    long long visited = 0;
-    const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
-    constexpr bool CAN_CACHE = LANES == 64;
-    DenseRegs<2, 4> regs;
-    bool cached = false;
-    if constexpr (CAN_CACHE) {
-        cached = dense_cacheable<LANES, 2, 4>(meta);
-        if (cached) dense_cache_load<LANES, 2, 4>(meta, w, a, regs);
-    }
-#ifdef MZ_STAMPS
-    long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_in = 0, st_mm = 0, st_t;
-#define MZ_STAMP(acc) { long long n_ = clock64(); acc += n_ - st_t; st_t = n_; }
-    st_t = clock64();
-#else
-#define MZ_STAMP(acc)
-#endif
-    for (int s = 0; s < n_sims; s++) {
-        int leaf = first_leaf + s;
-        int action, ntp, depth;
-        int parent;
-        if (wide) parent = descend_wide<RL, GUMBEL>(d, dc, m, a, leaf, nz, noise_max_calls, calls, &action, &ntp, &depth);
-        else parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
-        visited += depth + 1;
-        MZ_STAMP(st_sel)
-        // inputs: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
-        const float *ph = hid + (long long)parent * H;
-        for (int i = a; i < H; i += LANES) sc[net.io[0] + i] = ph[i];
-        for (int i = a; i < asz; i += LANES) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
-        lds_fence();
-        MZ_STAMP(st_in)
-        if (CAN_CACHE && cached) dense_run_cached<2, 4>(regs, sc);
-        else dense_run<LANES>(meta, w, sc, a);
-        MZ_STAMP(st_net)
-        minmax_to<LANES>(sc + net.io[2], H, ngroups, a, hid + (long long)leaf * H, nullptr);
-        MZ_STAMP(st_mm)
-        double value, reward;
-        support_to_scalar2<LANES>(sc + net.io[5], sc + net.io[3], sup, a, &value, &reward);
-        float lg = on ? sc[net.io[4] + a] : 0.0f;
-        MZ_STAMP(st_epi)
-        expand_backup<LANES, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
-        if constexpr (TREE_LDS) lds_fence();
-        else __threadfence_block();
-        MZ_STAMP(st_bk)
-    }
-    if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
-        d.visit_total[t] += visited;
-    }
-    if constexpr (TREE_LDS) {
-        const int live = first_leaf + n_sims;
-        const int32_t *src = reinterpret_cast<const int32_t *>(m.nodes);
-        int32_t *dst = reinterpret_cast<int32_t *>(m_global.nodes);
-        for (int i = a; i < live * (d.L.rec / 4); i += LANES) dst[i] = src[i];
-        for (int i = a; i < live * H; i += LANES) hid_global[i] = hid[i];
-    }
-#ifdef MZ_STAMPS
-    if (a == 0) {  // diagnostic build only: cycle shares per phase, parked in the path buffer (dead after the search)
-        long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
-        o[0] = st_sel; o[1] = st_net; o[2] = st_epi; o[3] = st_bk; o[4] = st_in; o[5] = st_mm;
-    }
-#endif
-}
-
-// mcts/action_selection.py:52-70 (PUCT) / :121-138 (Gumbel) + mcts/tree.py:60-68: the action to play,
-// this lane's policy entry and q entry, and the root value returned by MCTS.search (mcts/mcts.py:252).
-template <int RL, bool GUMBEL>
-__device__ __forceinline__ int to_act_rule(const Dev &d, int t, int a, bool on, double temperature, double uu,
-                                           double *prob_out, double *q_out, double *root_value_out)
-{
-    const int A = d.L.A;
-    const double inf = __builtin_huge_val();
-    NodeStats s = load_node<GUMBEL>(d, tree_mem(d, t), 0, a, on);
-    bool legal = (d.legal[t] >> a) & 1ull;
-    int action;
-    double prob, qout;
-    if constexpr (!GUMBEL) {
-        int total = gsumi<RL>(on ? s.cv : 0);
-        int den = total > 1 ? total : 1;
-        double vp = total > 0 ? (double)s.cv / (double)den : 1.0 / (double)A;
-        const double tiny = 2.2250738585072014e-308;
-        double lg = log(vp > tiny ? vp : tiny);
-        double mx = gmax<RL>(on ? lg : -inf);
-        double tt = temperature > 1e-27 ? temperature : 1e-27;
-        lg = (lg - mx) / tt;
-        double e = on ? exp(lg) : 0.0;
-        double es = gsum_np<RL, double>(e, a, A);
-        prob = e / es;
-        // legacy np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
-        double acc = 0.0, mine = 0.0;
-        for (int i = 0; i < A; i++) { acc += __shfl(prob, i, RL); if (a == i) mine = acc; }
-        mine = mine / acc;
-        int idx = gsumi<RL>((on && mine <= uu) ? 1 : 0);
-        action = idx < A ? idx : A - 1;
-        qout = s.r + d.discount * s.v;
-    } else {
-        int vsum;
-        double cq = qt_completed_mix<RL>(d, s, a, on, &vsum);
-        int considered = gmaxi<RL>(on ? s.cv : -2147483647);
-        double sc = gumbel_score<RL>(s, on, on ? d.gumbel[(long long)t * A + a] : 0.0, cq, considered);
-        if (!on || !legal) sc = -inf;
-        action = gargmax<RL>(sc, on ? a : 0x7fffffff);
-        double x = s.prior + cq;
-        double mx = gmax<RL>(on ? x : -inf);
-        x = legal ? x - mx : -1.7976931348623157e308;
-        double e = on ? exp(x) : 0.0;
-        double es = gsum_np<RL, double>(e, a, A);
-        prob = e / es;
-        qout = cq;
-    }
-    *prob_out = prob; *q_out = qout; *root_value_out = s.nval;
-    return action;
-}
-
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, const double *u,
-                                                      int32_t *out_action, double *out_probs,
-                                                      double *out_root_value, double *out_q)
-{
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    const int A = d.L.A;
-    bool on = a < A;
-    double prob, qout, rv;
-    int action = to_act_rule<RL, GUMBEL>(d, t, a, on, temperature, u ? u[t] : 0.0, &prob, &qout, &rv);
-    if (on) {
-        out_probs[(long long)t * A + a] = prob;
-        if (out_q) out_q[(long long)t * A + a] = qout;
-    }
-    if (a == 0) { out_action[t] = action; out_root_value[t] = rv; }
-}
-
-// ---------------------------------------------------------------------------- self-play step
-// Final action rule fused with the environment step of self_play.py:92-113 for every env of the batch:
-// act, game.step(action), hand the trajectory record of this move to the caller, restart finished
-// games.  Environment state is caller-owned device memory (mz_env_state in the header).
-struct EnvDev {
-    int kind, max_moves, stale, obs_size;
-    void *state;
-    int32_t *mover, *to_play;
-    uint8_t *legal;
-    float *cur_obs, *search_obs;
-    int32_t *moves;
-    const double *reset_state;
-};
-
-// games/tictactoe.py:14-81 + games/game.py:56-74.  Returns terminated; winner: -2 = none yet.
-__device__ __forceinline__ bool tictactoe_step(signed char *b, int *mover, int action, float *reward)
-{
-    b[action] = (signed char)*mover;  // no occupancy check, like the reference
-    *mover = -*mover;
-    int winner = -2;
-    bool term = false;
-    const int lines[8][3] = {{0, 3, 6}, {1, 4, 7}, {2, 5, 8}, {0, 1, 2}, {3, 4, 5}, {6, 7, 8}, {0, 4, 8}, {2, 4, 6}};
-    for (int i = 0; i < 8; i++) {  // columns, rows, diagonal, anti-diagonal: first complete line wins
-        int sline = b[lines[i][0]] + b[lines[i][1]] + b[lines[i][2]];
-        if (sline == 3 || sline == -3) { term = true; winner = sline / 3; break; }
-    }
-    int filled = 0;
-    for (int i = 0; i < 9; i++) filled += b[i] != 0;
-    if (filled == 9) { term = true; winner = 0; }  // a board-filling win is scored as a tie
-    *reward = (winner != -2 && winner != 0) ? 1.0f : 0.0f;
-    return term;
-}
-
-__device__ __forceinline__ void tictactoe_observe(const signed char *b, int mover, float *obs, uint8_t *legal)
-{
-    for (int i = 0; i < 9; i++) {
-        obs[i] = b[i] == -1 ? 1.0f : 0.0f;
-        obs[9 + i] = b[i] == 1 ? 1.0f : 0.0f;
-        obs[18 + i] = (float)mover;
-        legal[i] = b[i] == 0;
-    }
-}
-
-// CartPole-v1 per the public gymnasium specification (games/cartpole.py:9-48 delegates to it): Euler,
-// tau 0.02, float64 state, float32 observation, reward 1 per step, terminated outside +-2.4 / +-12 degrees.
-__device__ __forceinline__ bool cartpole_step(double *s, int action)
-{
-    const double gravity = 9.8, masspole = 0.1, total_mass = 1.1, length = 0.5;
-    const double polemass_length = masspole * length, force_mag = 10.0, tau = 0.02;
-    const double theta_thr = 12 * 2 * 3.141592653589793 / 360, x_thr = 2.4;
-    double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
-    double force = action == 1 ? force_mag : -force_mag;
-    double costheta = cos(theta), sintheta = sin(theta);
-    double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
-    double thetaacc = (gravity * sintheta - costheta * temp) /
-                      (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
-    double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
-    x = x + tau * x_dot; x_dot = x_dot + tau * xacc;
-    theta = theta + tau * theta_dot; theta_dot = theta_dot + tau * thetaacc;
-    s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
-    return x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr;
-}
-
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, double temperature, const double *u,
-                                                       int32_t *out_action, double *out_probs,
-                                                       double *out_root_value, float *out_obs_before,
-                                                       float *out_reward, uint8_t *out_done,
-                                                       int32_t *out_to_play)
-{
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
-    const int A = d.L.A, OS = e.obs_size;
-    bool on = a < A;
-    double prob, qout, rv;
-    int action = to_act_rule<RL, GUMBEL>(d, t, a, on, temperature, u ? u[t] : 0.0, &prob, &qout, &rv);
-    if (on) out_probs[(long long)t * A + a] = prob;
-    if (a != 0) return;
-    out_action[t] = action;
-    out_root_value[t] = rv;
-    out_to_play[t] = e.to_play[t];
-    float *cur = e.cur_obs + (long long)t * OS, *srch = e.search_obs + (long long)t * OS;
-    uint8_t *legal = e.legal + (long long)t * A;
-    if (out_obs_before) for (int i = 0; i < OS; i++) out_obs_before[(long long)t * OS + i] = cur[i];
-    // the reference searches the NEXT move from the observation saved with this one (self_play.py:86-91,108)
-    if (e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
-    float reward;
-    bool term;
-    if (e.kind == 1) {
-        signed char *b = reinterpret_cast<signed char *>(e.state) + (long long)t * 9;
-        int mover = e.mover[t];
-        term = tictactoe_step(b, &mover, action, &reward);
-        int moves = e.moves[t] + 1;
-        bool done = term || moves > e.max_moves;
-        if (done) {  // BoardGame.reset (games/game.py:65-71)
-            for (int i = 0; i < 9; i++) b[i] = 0;
-            mover = -1; moves = 0;
-        }
-        e.mover[t] = mover; e.moves[t] = moves;
-        e.to_play[t] = mover == -1 ? 0 : 1;
-        tictactoe_observe(b, mover, cur, legal);
-        if (done || !e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
-        out_done[t] = done;
-    } else {
-        double *s = reinterpret_cast<double *>(e.state) + (long long)t * 4;
-        term = cartpole_step(s, action);
-        reward = 1.0f;
-        int moves = e.moves[t] + 1;
-        bool done = term || moves > e.max_moves;
-        if (done) {
-            for (int i = 0; i < 4; i++) s[i] = e.reset_state[(long long)t * 4 + i];
-            moves = 0;
-        }
-        e.moves[t] = moves;
-        for (int i = 0; i < 4; i++) cur[i] = (float)s[i];
-        if (done || !e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
-        out_done[t] = done;
-    }
-    out_reward[t] = reward;
-}
-
-// mcts/mcts.py:22-31 + utils/game_utils.py:71-78 for B roots (root_prior in tree_ops.h).
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_root_prepare(int B, int A, const float *logits,
-                                                            const double *dirichlet, double frac,
-                                                            const uint8_t *legal, int shift_and_mask,
-                                                            void *out)
-{
-    int gid = (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / LANES), a = threadIdx.x % LANES;
-    if (gid >= B) return;
-    bool on = a < A;
-    long long k = (long long)gid * A + a;
-    float lg = on ? logits[k] : 0.0f;
-    bool lgl = on && (legal ? legal[k] != 0 : true);
-    double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
-    double pr = root_prior<RL, GUMBEL>(lg, on, lgl, di, frac, a, A, shift_and_mask != 0);
-    if (on) {
-        if (GUMBEL) reinterpret_cast<float *>(out)[k] = (float)pr;
-        else reinterpret_cast<double *>(out)[k] = pr;
-    }
-}
-
-// One rule at one node, for the module-level functions of the drop-in package.
-template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int depth, int which,
-                                                 const double *uniform, double *out_vec, int32_t *out_action)
-{
-    int a = threadIdx.x % LANES;
-    if (threadIdx.x >= LANES) return;
-    bool on = a < d.L.A;
-    if (which == 3) {  // selection
-        int child;
-        double u = (uniform && on) ? uniform[a] : 0.0;
-        DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, nullptr);
-        int act = select_at<RL, GUMBEL>(d, dc, tree_mem(d, t), node, depth, a, on, u, &child);
-        if (a == 0) *out_action = act;
-        return;
-    }
-    NodeStats s = load_node<GUMBEL>(d, tree_mem(d, t), node, a, on);
-    double r;
-    if (which == 0) {
-        r = qt_parent_siblings<RL>(d, s, on);
-    } else {
-        int vsum;
-        if constexpr (GUMBEL) {
-            if (which == 1) {
-                r = qt_completed_mix<RL>(d, s, a, on, &vsum);
-            } else {
-                vsum = gsumi<RL>(on ? s.cv : 0);
-                r = mixed_value<RL>(d, s, a, on, s.r + d.discount * s.v, vsum);
-            }
-        } else {
-            r = 0.0;
-        }
-    }
-    if (on) out_vec[a] = r;
-}
-
-// MCTS.backward (mcts/mcts.py:143-164) from an arbitrary node, walking the parent links; one lane.
-__global__ void k_node_backward(Dev d, int t, int leaf, int to_play)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const TreeMem m = tree_mem(d, t);
-    double leaf_value = view(d, m, leaf).hdr->value;
-    for (int guard = 0; leaf != 0 && guard <= d.L.S; guard++) {
-        RowView lf = view(d, m, leaf);
-        int p = lf.hdr->parent, a = lf.hdr->afp;
-        if (p < 0 || p >= d.L.N || a < 0 || a >= d.L.A) { atomicExch(d.err, 1); return; }
-        RowView pw = view(d, m, p);
-        double reward = pw.crew[a];
-        int pv = pw.hdr->visits;
-        double sv = pw.hdr->to_play == to_play ? leaf_value : -leaf_value;
-        pw.hdr->value = (pw.hdr->value * (double)pv + sv) / (double)(pv + 1);
-        pw.hdr->visits = pv + 1;
-        pw.cval[a] = lf.hdr->value;
-        pw.cvis[a] += 1;
-        leaf_value = reward + d.discount * leaf_value;
-        leaf = p;
-    }
-}
-
-__global__ void k_stats(Dev d, long long *out_node_visits, int32_t *out_noise_calls)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= d.B) return;
-    if (out_node_visits) out_node_visits[t] = d.visit_total[t];
-    if (out_noise_calls) out_noise_calls[t] = (int32_t)d.noise_calls[t];
-}
 
 // ============================================================================ host side
 

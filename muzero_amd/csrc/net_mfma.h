@@ -9,7 +9,7 @@
 // separated by a workgroup barrier.  float32 in, float32 accumulate: a k-ordered fma chain per
 // output, same rounding class as the reference's float32 network.
 #pragma once
-#include "tree_ops.h"
+#include "dense_net.h"
 
 namespace mz {
 
