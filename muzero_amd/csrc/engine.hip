@@ -370,7 +370,14 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
     }
     if (net_kind == MZ_NET_DENSE) {
         if (!c->net.meta) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network first)");
-        size_t lds = ((size_t)c->net.n_data + c->net.n_meta + (size_t)(MZ_BLOCK / c->lanes) * c->net_scratch) * 4;
+        // Groups per block: as many as fill a block, but small batches of whole-wave groups use smaller
+        // blocks so that they spread over all CUs (256 trees -> 256 one-wave blocks).
+        int gpb = MZ_BLOCK / c->lanes;
+        if (c->lanes == 64)
+            while (gpb > 1 && (c->B + gpb - 1) / gpb < 256) gpb >>= 1;
+        if (const char *e = getenv("MZ_GROUPS_PER_BLOCK")) { int v = atoi(e); if (v >= 1 && v <= MZ_BLOCK / c->lanes) gpb = v; }
+        const unsigned n_blocks = (unsigned)((c->B + gpb - 1) / gpb), n_threads = (unsigned)(gpb * c->lanes);
+        size_t lds = ((size_t)c->net.n_data + c->net.n_meta + (size_t)gpb * c->net_scratch) * 4;
         if (lds > 160 * 1024)
             return fail(MZ_ERR_ARG, "mz_search_run: network does not fit in LDS for the fused search; use the step API");
         // Small batches are latency-bound: whole-wave groups keep their trees in LDS when one block per CU
@@ -378,9 +385,9 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         const Layout &L = c->d.L;
         const int tree_lds = ((L.N * L.rec + 15) & ~15) + ((L.N * L.H * 4 + 15) & ~15) + ((L.S * 4 + 15) & ~15) +
                              ((L.N * 4 + 15) & ~15);
-        const size_t lds_tree = ((lds + 15) & ~(size_t)15) + (size_t)(MZ_BLOCK / c->lanes) * tree_lds;
+        const size_t lds_tree = ((lds + 15) & ~(size_t)15) + (size_t)gpb * tree_lds;
         const size_t lds_static = (size_t)MZ_BLOCK * 8 + (c->cfg.gumbel ? 32 : (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8);
-        bool tree_in_lds = c->lanes == 64 && grid_for(c->B, 64) <= 256 && lds_tree + lds_static <= 160 * 1024;
+        bool tree_in_lds = c->lanes == 64 && n_blocks <= 256 && lds_tree + lds_static <= 160 * 1024;
         if (const char *e = getenv("MZ_TREE_LDS")) tree_in_lds = tree_in_lds && atoi(e) != 0;
         hipError_t attr_err = hipSuccess;
         dispatch_shape(c->lanes, c->rl, c->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) {
@@ -389,7 +396,7 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
             auto launch = [&](auto kern, size_t bytes, int tree_bytes) {
                 attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-                hipLaunchKernelGGL(kern, dim3(grid_for(c->B, LN)), dim3(MZ_BLOCK), bytes, (hipStream_t)stream, c->d,
+                hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(n_threads), bytes, (hipStream_t)stream, c->d,
                                    c->net, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch,
                                    tree_bytes);
             };
@@ -780,11 +787,8 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
     if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no network uploaded (call mz_set_network_mfma first)");
     int leaf = c->n_expanded + 1;
     size_t lds = (size_t)c->mnet.stride * MZ_NET_TM * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // per launch, like the other kernels with large dynamic LDS: the attribute belongs to the current device
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_net_step, dim3((c->B + MZ_NET_TM - 1) / MZ_NET_TM), dim3(MZ_NET_NT), lds, (hipStream_t)stream, c->d,
                        c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
     if ((rc = launch_status("mz_expand_backup_net"))) return rc;

@@ -69,8 +69,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     float *w = lds;                                                  // [n_data]
     int32_t *meta = reinterpret_cast<int32_t *>(lds + net.n_data);   // [n_meta]
     float *scratch0 = lds + net.n_data + net.n_meta;
-    for (int i = threadIdx.x; i < net.n_data; i += MZ_BLOCK) w[i] = net.data[i];
-    for (int i = threadIdx.x; i < net.n_meta; i += MZ_BLOCK) meta[i] = net.meta[i];
+    // the block may be launched with fewer than MZ_BLOCK threads (a multiple of LANES): small batches
+    // then spread over more CUs
+    const int n_threads = blockDim.x, groups_per_block = n_threads / LANES;
+    for (int i = threadIdx.x; i < net.n_data; i += n_threads) w[i] = net.data[i];
+    for (int i = threadIdx.x; i < net.n_meta; i += n_threads) meta[i] = net.meta[i];
     float *sc = scratch0 + (size_t)(threadIdx.x / LANES) * scratch_floats;
     for (int i = threadIdx.x % LANES; i < scratch_floats; i += LANES) sc[i] = 0.0f;
     __shared__ __align__(16) double s_bk[MZ_BLOCK];
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
     const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
     __syncthreads();
-    int t, a;
-    if (!group_ids<LANES>(d, &t, &a)) return;
+    const int t = (int)blockIdx.x * groups_per_block + (int)threadIdx.x / LANES, a = threadIdx.x % LANES;
+    if (t >= d.B) return;
     const int A = d.L.A, H = d.L.H;
     bool on = a < A;
     const double *nz = noise ? noise + (long long)t * noise_max_calls * A : nullptr;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     const TreeMem m_global = m;
     if constexpr (TREE_LDS) {
         // region after the groups' activation scratch, 16-byte aligned: records | hidden | path
-        size_t base = ((size_t)(net.n_data + net.n_meta) + (size_t)(MZ_BLOCK / LANES) * scratch_floats) * 4;
+        size_t base = ((size_t)(net.n_data + net.n_meta) + (size_t)groups_per_block * scratch_floats) * 4;
         base = (base + 15) & ~(size_t)15;
         char *tl = reinterpret_cast<char *>(lds) + base + (size_t)(threadIdx.x / LANES) * tree_lds_bytes;
         const int rec_bytes = (d.L.N * d.L.rec + 15) & ~15, hid_bytes = (d.L.N * H * 4 + 15) & ~15;
