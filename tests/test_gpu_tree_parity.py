@@ -258,3 +258,37 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         eng.reset(np.zeros((5, 4)), np.zeros(5), None, np.zeros(5, np.int32), np.ones((5, 4)))  # B > max_batch
     eng.close()
+
+
+def test_result_is_independent_of_the_shard_layout():
+    """One context over all trees vs. the same trees split over 1, 2, 3 and 8 'ranks' (block partition of
+    muzero_amd.distributed.shard_range, tree_id0 = first global tree of the shard): the noise is keyed by the
+    global tree id, so every shard layout returns the same actions, values and visit counts."""
+    from muzero_amd.distributed import shard_range
+    rng = np.random.default_rng(21)
+    A, S, H, B = 2, 30, 4, 203
+    cfg = make_config(False, A, S, 1, 0.997)
+    hp = hashnet.HashNetParams(A, H, 4, 1, 1)
+    codes, legal = _batch_inputs(A, B, rng, partial=False)
+    dirichlet = rng.dirichlet([0.25] * A, size=B)
+    logits = np.stack([hashnet.logits_of(int(c), hp) for c in codes])
+    values = np.array([hashnet.value_of(int(c)) for c in codes])
+    hidden = np.stack([hashnet.hidden_of(int(c), hp) for c in codes])
+    to_play = np.zeros(B, np.int32)
+
+    def run(lo, hi):
+        eng = _engine(cfg, H, hi - lo, seed=17)
+        prior = eng.root_prepare(logits[lo:hi], legal[lo:hi], dirichlet[lo:hi], 0.25)
+        eng.reset(prior, values[lo:hi], hidden[lo:hi], to_play[lo:hi], legal[lo:hi], None, tree_id0=lo)
+        eng.search_hash(4, 1, 1)
+        action, value, probs, _ = eng.to_act(0.0)
+        nv, calls = eng.stats()
+        out = [x.cpu().numpy().copy() for x in (action, value, probs, nv, calls)]
+        eng.close()
+        return out
+
+    whole = run(0, B)
+    for world in (2, 3, 8):
+        parts = [run(*shard_range(B, r, world)) for r in range(world)]
+        for k in range(5):
+            np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), whole[k])
