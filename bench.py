@@ -42,6 +42,12 @@ def search_config(gumbel, A, S, players, gamma):
                            c_base=19625, c_init=1.25, dirichlet_alpha=0.25, exploration_frac=0.25)
 
 
+def atari_like_net_config():
+    return SimpleNamespace(network='mlp', observation_dim=[1, 1, 128], n_actions=18, n_stacked_observations=1,
+                           encoding_size=256, fc_reward_layers=[256], fc_policy_layers=[256], fc_value_layers=[256],
+                           fc_representation_layers=[256], fc_hidden_state_layers=[256], support_limit=300)
+
+
 def tictactoe_net_config():
     return SimpleNamespace(network='resnet', observation_dim=[3, 3, 3], n_actions=9, n_stacked_observations=1,
                            blocks=1, channels=16, reduced_channels_reward=8, reduced_channels_policy=8,
@@ -58,6 +64,7 @@ WORKLOADS = {
     'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), whole search in one launch, leaves evaluated on the matrix cores (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
+    'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), leaves on the matrix cores, backup fused with the next selection (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma_step'),
     'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
 }
 
@@ -126,6 +133,13 @@ def main():
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
         eng.set_network(packed)
         obs = torch.as_tensor(rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32), device=dev)
+    elif leaf == 'mfma_step':
+        from muzero_amd.packing import pack_network_mfma
+        net = MuZeroNetwork(atari_like_net_config(), seed=0).to(dev)
+        H = net.H
+        eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
+        eng.set_network_mfma(*pack_network_mfma(net))
+        obs = torch.as_tensor(rng.standard_normal((B, 128)).astype(np.float32), device=dev)
     elif leaf in ('step', 'mfma'):
         from muzero_amd.packing import pack_network_mfma
         net = MuZeroNetwork(tictactoe_net_config(), seed=0).to(dev)
@@ -173,7 +187,7 @@ def main():
             return out
         if leaf == 'mlp':
             eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
-        elif leaf in ('step', 'mfma'):
+        elif leaf in ('step', 'mfma', 'mfma_step'):
             lg0, hid0, val0 = net.initial_flat(obs)
             prior = eng.root_prepare(lg0, legal, dirichlet, 0.25)
             eng.reset(prior, val0, hid0, to_play, legal, gnoise, tree_id0=tree_id0)
@@ -186,6 +200,10 @@ def main():
             eng.search_net()
         elif leaf == 'mfma':
             eng.search_mfma()
+        elif leaf == 'mfma_step':
+            eng.select(want_hidden=False)
+            for _ in range(S):
+                eng.expand_backup_net(select_next=True)
         elif leaf == 'step':
             for _ in range(S):
                 parent, action, phid = eng.select()
@@ -235,7 +253,7 @@ def main():
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
         'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': 'k_search_mfma', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
+                                'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},

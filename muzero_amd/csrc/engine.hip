@@ -748,8 +748,8 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     if (io_h[6] != c->cfg.hidden_size || io_h[7] != c->cfg.n_actions)
         return fail(MZ_ERR_ARG, "mz_set_network_mfma: network hidden size / action count differ from the context's");
     if (io_h[10] < 1 || io_h[6] % io_h[10]) return fail(MZ_ERR_ARG, "mz_set_network_mfma: hidden size not divisible by normalisation groups");
-    if (stride % 64 != 4) return fail(MZ_ERR_ARG, "mz_set_network_mfma: stride must be 4 mod 64");
-    if ((size_t)stride * MZ_NET_TM * 4 > 160 * 1024) return fail(MZ_ERR_ARG, "mz_set_network_mfma: activations of a 32-tree tile exceed LDS");
+    if (stride % 8 != 4) return fail(MZ_ERR_ARG, "mz_set_network_mfma: stride must be 4 times an odd number");
+    if ((size_t)stride * 16 * 4 > 160 * 1024) return fail(MZ_ERR_ARG, "mz_set_network_mfma: activations of a 16-tree tile exceed LDS");
     if (level_start_h[n_levels] != n_tiles) return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent tile table");
     for (int s = 0; s < n_steps; s++) {
         const int32_t *st = steps_h + 12 * s;
@@ -786,10 +786,13 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
     if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no pending selection (call mz_select first)");
     if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no network uploaded (call mz_set_network_mfma first)");
     int leaf = c->n_expanded + 1;
-    size_t lds = (size_t)c->mnet.stride * MZ_NET_TM * 4;
+    // 32 trees per block while their activations fit in LDS, else 16
+    const int tm = (size_t)c->mnet.stride * 32 * 4 <= 160 * 1024 ? 32 : 16;
+    size_t lds = (size_t)c->mnet.stride * tm * 4;
+    auto kern = tm == 32 ? k_net_step<32> : k_net_step<16>;
     // per launch, like the other kernels with large dynamic LDS: the attribute belongs to the current device
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_net_step, dim3((c->B + MZ_NET_TM - 1) / MZ_NET_TM), dim3(MZ_NET_NT), lds, (hipStream_t)stream, c->d,
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream, c->d,
                        c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
     if ((rc = launch_status("mz_expand_backup_net"))) return rc;
     select_next = select_next && leaf < c->cfg.n_simulations;

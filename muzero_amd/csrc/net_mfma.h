@@ -2,7 +2,7 @@
 //
 // One workgroup (4 waves) evaluates the lowered network (dense program, MFMA layout of
 // muzero_amd/packing.py) for a tile of TM = 32 trees.  The tile's activations live in LDS
-// ([32][stride] floats, stride == 4 mod 64 so the 16-byte operand reads are conflict-free); weights
+// ([32][stride] floats, stride = 4 x odd so the 16 rows of an operand read start in 16 different bank groups); weights
 // stream from L2 in v_mfma_f32_16x16x4_f32 operand order, one 16-byte load per lane per four k-steps, and every loaded fragment is used for both 16-row halves
 // of the tile (two independent accumulators, which also covers the MFMA's dependent latency).
 // Within a level the (step, column tile) jobs are dealt round-robin to the four waves; levels are
@@ -178,23 +178,25 @@ __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *r
 // recurrent_inference (network.py:105-126) for every tree's pending selection, then nothing else:
 // outputs go to the leaf's hidden slot and to the per-tree logits/value/reward buffers that
 // k_expand_backup consumes.
-__global__ __launch_bounds__(MZ_NET_NT) void k_net_step(Dev d, MfmaNet net, int leaf, float *out_logits,
+// TM = trees per block: 32, or 16 for networks whose 32-tree activation tile exceeds LDS.
+template <int TM>
+__global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int leaf, float *out_logits,
                                                    double *out_value, double *out_reward)
 {
-    extern __shared__ __align__(16) float act[];  // [MZ_NET_TM][stride]
+    extern __shared__ __align__(16) float act[];  // [TM][stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = tid / 16, a = tid % 16, t = blockIdx.x * MZ_NET_TM + i;
+    const int i = tid / 16, a = tid % 16, t = blockIdx.x * TM + i;
     const int H = net.io[6], A = net.io[7];
     const bool live = t < d.B;
     float *row = act + i * net.stride;
-    tile_zero<MZ_NET_TM>(act, net.stride, tid);
+    tile_zero<TM>(act, net.stride, tid);
     __syncthreads();
     if (live) {
         int parent = d.sel_parent[t], action = d.sel_action[t];
         tile_stage_inputs(net, row, d.hidden + ((long long)t * d.L.N + parent) * H, action, a);
     }
     __syncthreads();
-    tile_run_levels<MZ_NET_TM>(net, act, wave, lane);
+    tile_run_levels<TM>(net, act, wave, lane);
     if (!live) return;
     double value, reward;
     tile_epilogue(net, row, a, d.hidden + ((long long)t * d.L.N + leaf) * H, &value, &reward);

@@ -155,24 +155,67 @@ class PackedMfma:
     level_start: np.ndarray  # int32 [n_levels + 1]
     wfrag: np.ndarray        # float32
     bias: np.ndarray         # float32 (each step padded to 16 columns)
-    stride: int              # activation floats per tree (== 4 mod 64: conflict-free 16-byte operand reads)
+    stride: int              # activation floats per tree (4 x an odd number: conflict-free 16-byte operand reads)
     slots: Dict[str, int]
     macs: int                # unpadded multiply-accumulates per tree
     padded_macs: int         # what the MFMA tiles actually compute per tree
 
 
-def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = None) -> PackedMfma:
-    aliases = aliases or {}
-    slots: Dict[str, int] = {}
-    sizes: Dict[str, int] = {}
-    level_of: Dict[str, int] = {}
+def _assign_slots(steps, inputs, aliases, keep):
+    """Offsets (in floats, multiples of 16) of every tensor in a tree's activation row, reusing the
+    space of tensors that are dead: a tensor lives from the level that writes it (inputs: level 0) to
+    the last level that reads it (`keep`: to the end).  Everything read or written at a level is
+    disjoint, since the waves of a block work on different jobs of that level at the same time."""
     al16 = lambda x: (int(x) + 15) // 16 * 16  # noqa: E731
-    off = 0
-    for name, size in inputs.items():
-        slots[name], sizes[name], level_of[name] = off, int(size), 0
-        off = al16(off + int(size))
+    base_of = {name: b for name, (b, _, _) in aliases.items()}
+    root = lambda n: base_of.get(n, n)  # noqa: E731
+    sizes = {n: int(sz) for n, sz in inputs.items()}
+    level_of = {n: 0 for n in inputs}
+    last_use = {n: 0 for n in inputs}
+    for s in steps:
+        lv = 1 + max(level_of[root(s.inp)], level_of[root(s.skip)] if s.skip else 0)
+        level_of[s.out], sizes[s.out] = lv, int(s.W.shape[0])
+        last_use[s.out] = lv
+        for r in (s.inp, s.skip):
+            if r:
+                last_use[root(r)] = max(last_use[root(r)], lv)
+    for n in keep:
+        last_use[root(n)] = 1 << 30
+    slots, live, end = {}, [], 0   # live: (offset, units of 16 floats, name)
+
+    def place(name):
+        nonlocal end
+        need = al16(sizes[name])
+        taken = sorted((o, o + n) for o, n, _ in live)
+        pos = 0
+        for lo, hi in taken:
+            if lo - pos >= need:
+                break
+            pos = max(pos, hi)
+        slots[name] = pos
+        live.append((pos, need, name))
+        end = max(end, pos + need)
+
+    for n in inputs:
+        place(n)
+    for lv in range(1, max(level_of.values(), default=0) + 1):
+        live[:] = [x for x in live if last_use[x[2]] >= lv]
+        for s in steps:
+            if level_of[s.out] == lv:
+                place(s.out)
+    for name, (b, o, _) in aliases.items():
+        slots[name] = slots[b] + o
+    return slots, level_of, end
+
+
+def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = None,
+              keep: Sequence[str] = ()) -> PackedMfma:
+    """keep: tensors that must survive to the end of the program (what the epilogue reads)."""
+    aliases = aliases or {}
+    slots, level_of, end = _assign_slots(steps, inputs, aliases, keep)
+    sizes: Dict[str, int] = {n: int(sz) for n, sz in inputs.items()}
     for name, (base, o, size) in aliases.items():
-        slots[name], sizes[name], level_of[name] = slots[base] + o, int(size), 0
+        sizes[name] = int(size)
     table, wblobs, bblobs = [], [], []
     w_off = b_off = macs = padded = 0
     per_level: Dict[int, list] = {}
@@ -180,10 +223,8 @@ def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple]
         N, K = (int(x) for x in s.W.shape)
         if sizes[s.inp] != K:
             raise ValueError(f'step {s.out}: input {s.inp} has {sizes[s.inp]} floats, weight expects {K}')
-        lv = 1 + max(level_of[s.inp], level_of[s.skip] if s.skip else 0)
-        level_of[s.out] = lv
-        slots[s.out], sizes[s.out] = off, N
-        off = al16(off + N)   # 16-float slots: a tile's padded columns never spill into a neighbour
+        lv = level_of[s.out]
+        sizes[s.out] = N
         k16, nct = (K + 15) // 16, (N + 15) // 16
         Wp = np.zeros((nct * 16, k16 * 16), np.float32)
         Wp[:N, :K] = s.W.detach().cpu().numpy()
@@ -203,8 +244,13 @@ def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple]
         for (si, ct) in per_level.get(lv, []):
             tiles += [si, ct]
         level_start.append(len(tiles) // 2)
-    stride = off + 16                    # inputs are read up to 15 floats past their end (zero weights)
-    stride += (4 - stride) % 64          # == 4 (mod 64)
+    # an input is read in blocks of 16 floats, i.e. up to 15 floats past its own end, where the weights
+    # are zero but the values must exist: the row covers the furthest such read
+    tab = np.asarray(table, np.int64).reshape(-1, 12)
+    stride = max(end, int((tab[:, 3] + tab[:, 2] * 16).max()) if len(tab) else 0)
+    stride = (stride + 3) // 4 * 4
+    if stride % 8 == 0:
+        stride += 4                      # 4 x odd: rows start 4 x (odd multiple) banks apart
     return PackedMfma(np.asarray(table, np.int32), np.asarray(tiles, np.int32), np.asarray(level_start, np.int32),
                       np.concatenate(wblobs), np.concatenate(bblobs), int(stride), slots, macs, padded)
 
@@ -213,7 +259,8 @@ def pack_network_mfma(net):
     """Recurrent program (dynamics + prediction of the parent state) of a lowered network in MFMA
     layout, with the io vector of PackedNetwork.io()."""
     H, asz = net.H, net.action_size
-    pm = pack_mfma(list(net.dyn.steps) + list(net.pred.steps), {'xa': H + asz}, {'hidden': ('xa', 0, H)})
+    pm = pack_mfma(list(net.dyn.steps) + list(net.pred.steps), {'xa': H + asz}, {'hidden': ('xa', 0, H)},
+                   keep=('next_raw', 'reward_logits', 'policy_logits', 'value_logits'))
     io = np.asarray([pm.slots['xa'], pm.slots['xa'] + H, pm.slots['next_raw'], pm.slots['reward_logits'],
                      pm.slots['policy_logits'], pm.slots['value_logits'], H, net.A, asz,
                      2 * net.support_limit + 1, net.norm_groups, net.obs_size], np.int32)

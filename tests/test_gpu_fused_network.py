@@ -140,15 +140,25 @@ def test_network_too_large_for_lds_is_rejected():
     eng.close()
 
 
-@pytest.mark.parametrize('name,B', [('resnet_tictactoe', 100), ('mlp_synthetic', 77), ('mlp_cartpole', 33)])
+@pytest.mark.parametrize('name,B', [('resnet_tictactoe', 100), ('mlp_synthetic', 77), ('mlp_cartpole', 33),
+                                    ('mlp_wide256', 40)])
 def test_mfma_leaf_evaluation_matches_torch_network(name, B):
     """Leaves evaluated by the matrix-core kernel vs the same lowered network run by torch:
     first-simulation outputs within 1e-5 (hidden 1e-4), whole searches agree tree by tree."""
     from muzero_amd.engine import SearchEngine
     from muzero_amd.packing import pack_network_mfma
-    z, net = load_net(name)
+    if name == 'mlp_wide256':   # hidden 256, 601-bin supports: only a 16-tree activation tile fits in LDS
+        from types import SimpleNamespace
+        wide = SimpleNamespace(network='mlp', observation_dim=[1, 1, 128], n_actions=18, n_stacked_observations=1,
+                               encoding_size=256, fc_reward_layers=[256], fc_policy_layers=[256], fc_value_layers=[256],
+                               fc_representation_layers=[256], fc_hidden_state_layers=[256], support_limit=300)
+        net = MuZeroNetwork(wide, seed=0)
+        z = {'obs': np.random.default_rng(0).normal(size=(64, 1, 1, 128))}
+        gnet = MuZeroNetwork(wide, net.state_dict()).to('cuda')
+    else:
+        z, net = load_net(name)
+        gnet = MuZeroNetwork(net_config(name), net.state_dict()).to('cuda')
     pm, io = pack_network_mfma(net)
-    gnet = MuZeroNetwork(net_config(name), net.state_dict()).to('cuda')
     A, S = net.A, 24
     gumbel = name == 'resnet_tictactoe'
     cfg = make_config(gumbel, A, S, 2 if gumbel else 1, 1 if gumbel else 0.997)
