@@ -346,10 +346,12 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
     if (net_kind == MZ_NET_MFMA) {
         if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network_mfma first)");
         if (c->rl > 16) return fail(MZ_ERR_ARG, "mz_search_run: the matrix-core search serves at most 16 actions; use the step API");
-        constexpr int tm = MZ_NET_TM;  // 16-tree tiles (two blocks per CU) measured no faster on the 3x3-board ResNet
+        // 32-tree tiles: 16-tree tiles (two or three blocks per CU) were measured no faster - each weight
+        // fragment then serves one row block instead of two
+        constexpr int tm = 32;
         const size_t lds = (size_t)c->mnet.stride * tm * 4;
         if (lds + (size_t)tm * 16 * 8 > 160 * 1024)
-            return fail(MZ_ERR_ARG, "mz_search_run: activations of a tile do not fit in LDS beside the backup staging; use the step API");
+            return fail(MZ_ERR_ARG, "mz_search_run: activations of a 32-tree tile do not fit in LDS beside the backup staging; use the step API");
         hipError_t attr_err = hipSuccess;
         auto launch = [&](auto kern) {
             attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -230,6 +230,12 @@ __global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[tt];
     long long visited = 0;
     __syncthreads();
+#ifdef MZ_STAMPS
+    long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_t = clock64();
+#define MZ_MSTAMP(acc) { long long n_ = clock64(); acc += n_ - st_t; st_t = n_; }
+#else
+#define MZ_MSTAMP(acc)
+#endif
     for (int s = 0; s < n_sims; s++) {
         const int leaf = first_leaf + s;
         int parent = 0, action = 0, ntp = 0, depth = 0;
@@ -238,8 +244,11 @@ __global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int
             visited += depth + 1;
             tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
         }
+        MZ_MSTAMP(st_a)
         __syncthreads();
+        MZ_MSTAMP(st_b)
         tile_run_levels<TM>(net, act, wave, lane);
+        MZ_MSTAMP(st_c)
         if (live) {
             double value, reward;
             tile_epilogue(net, row, a, hid + (long long)leaf * H, &value, &reward);
@@ -247,7 +256,14 @@ __global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int
             expand_backup<16, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
             __threadfence_block();
         }
+        MZ_MSTAMP(st_d)
     }
+#ifdef MZ_STAMPS
+    if (live && a == 0) {  // diagnostic build only: [descend+stage, barrier wait, network, epilogue+backup] cycles
+        long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
+        o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = st_d;
+    }
+#endif
     if (live && a == 0) {
         if constexpr (!GUMBEL) d.noise_calls[t] = calls;
         d.visit_total[t] += visited;

@@ -1,0 +1,30 @@
+"""Diagnostic: per-phase cycle shares of the matrix-core search kernel (needs the -DMZ_STAMPS build)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, '.')
+os.environ['MUZERO_AMD_LIB'] = os.path.abspath('muzero_amd/libmuzero_amd_stamps.so')
+import bench
+from muzero_amd.engine import SearchEngine, lib
+from muzero_amd.network import MuZeroNetwork
+from muzero_amd.packing import pack_network_mfma
+
+B, S, A = 16384, 100, 9
+cfg = bench.search_config(True, A, S, 2, 1)
+net = MuZeroNetwork(bench.tictactoe_net_config(), seed=0).to('cuda')
+eng = SearchEngine(cfg, net.H, B, seed=0)
+eng.set_network_mfma(*pack_network_mfma(net))
+rng = np.random.default_rng(1)
+boards = rng.integers(0, 3, size=(B, 9)) - 1
+planes = np.stack([(boards == -1), (boards == 1), np.ones_like(boards) * -1], axis=1).astype(np.float32)
+obs = torch.as_tensor(planes.reshape(B, 27), device='cuda')
+g = rng.gumbel(size=(B, A))
+for _ in range(2):
+    lg0, hid0, val0 = net.initial_flat(obs)
+    prior = eng.root_prepare(lg0, np.ones((B, A)))
+    eng.reset(prior, val0, hid0, np.zeros(B, np.int32), np.ones((B, A)), g)
+    eng.search_mfma()
+buf = np.zeros((B, S), np.int32)
+lib().mz_debug_read_path(C.c_void_p(eng._ctx), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes))
+st = buf.view(np.int64).reshape(B, S // 2)[:, :4].astype(np.float64)
+print('cycles per simulation (clock64 ticks), mean over trees: descend+stage %.0f  barrier wait %.0f  network %.0f  epilogue+backup %.0f  total %.0f'
+      % (*(st.mean(0) / S), st.sum(1).mean() / S))
