@@ -65,6 +65,7 @@ WORKLOADS = {
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
     'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), leaves on the matrix cores, backup fused with the next selection (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma_step'),
+    'cfg5t': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), leaves evaluated by torch ops (comparison)', False, 18, 200, 1, 0.997, 1024, 'step5'),
     'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
 }
 
@@ -133,7 +134,7 @@ def main():
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
         eng.set_network(packed)
         obs = torch.as_tensor(rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32), device=dev)
-    elif leaf == 'mfma_step':
+    elif leaf in ('mfma_step', 'step5'):
         from muzero_amd.packing import pack_network_mfma
         net = MuZeroNetwork(atari_like_net_config(), seed=0).to(dev)
         H = net.H
@@ -187,7 +188,7 @@ def main():
             return out
         if leaf == 'mlp':
             eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
-        elif leaf in ('step', 'mfma', 'mfma_step'):
+        elif leaf in ('step', 'mfma', 'mfma_step', 'step5'):
             lg0, hid0, val0 = net.initial_flat(obs)
             prior = eng.root_prepare(lg0, legal, dirichlet, 0.25)
             eng.reset(prior, val0, hid0, to_play, legal, gnoise, tree_id0=tree_id0)
@@ -204,7 +205,7 @@ def main():
             eng.select(want_hidden=False)
             for _ in range(S):
                 eng.expand_backup_net(select_next=True)
-        elif leaf == 'step':
+        elif leaf in ('step', 'step5'):
             for _ in range(S):
                 parent, action, phid = eng.select()
                 lg, nh, val, rew = net.recurrent_flat(phid, net.encode_actions(action))
@@ -253,7 +254,7 @@ def main():
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
         'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
+                                'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},

@@ -2,6 +2,7 @@
 // See include/muzero_amd.h; the kernels live in the headers included below.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -47,7 +48,10 @@ struct mz_ctx {
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
     MfmaNet mnet;       // MFMA-layout network (mz_set_network_mfma)
-    void *mnet_bufs[5];
+    void *mnet_bufs[7];  // steps, tiles, level_start, wfrag, bias, per-level job table, global activations
+    int mnet_max_k16;                  // widest layer input in blocks of 16 floats
+    std::vector<int> mnet_level_job0;  // first block of each level in the job table (+ total at the end)
+    bool mnet_tile_fits;               // a 16-tree activation tile fits in LDS (tile-resident kernels usable)
     float *leaf_logits; // [max_batch][A] outputs of the batched leaf evaluation
     double *leaf_value, *leaf_reward;
 };
@@ -751,7 +755,7 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
         return fail(MZ_ERR_ARG, "mz_set_network_mfma: network hidden size / action count differ from the context's");
     if (io_h[10] < 1 || io_h[6] % io_h[10]) return fail(MZ_ERR_ARG, "mz_set_network_mfma: hidden size not divisible by normalisation groups");
     if (stride % 8 != 4) return fail(MZ_ERR_ARG, "mz_set_network_mfma: stride must be 4 times an odd number");
-    if ((size_t)stride * 16 * 4 > 160 * 1024) return fail(MZ_ERR_ARG, "mz_set_network_mfma: activations of a 16-tree tile exceed LDS");
+    if (stride > (1 << 20)) return fail(MZ_ERR_ARG, "mz_set_network_mfma: unreasonable activation row");
     if (level_start_h[n_levels] != n_tiles) return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent tile table");
     for (int s = 0; s < n_steps; s++) {
         const int32_t *st = steps_h + 12 * s;
@@ -764,7 +768,36 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
         if (tiles_h[2 * i] < 0 || tiles_h[2 * i] >= n_steps || tiles_h[2 * i + 1] < 0 ||
             tiles_h[2 * i + 1] >= steps_h[12 * tiles_h[2 * i] + 9])
             return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad tile entry");
+    // job table of the per-level path: blocks of up to MZ_LVL_WAVES column tiles of one step, level by level
+    std::vector<int32_t> jobs;
+    std::vector<int> job0(1, 0);
+    for (int l = 0; l < n_levels; l++) {
+        for (int s = 0; s < n_steps; s++) {
+            const int32_t *st = steps_h + 12 * s;
+            if (st[0] != l) continue;
+            if (l == 0 && (st[3] < io_h[0] || st[3] + st[2] * 16 > stride))
+                return fail(MZ_ERR_ARG, "mz_set_network_mfma: a first-level step reads outside the network inputs");
+            if ((size_t)(st[2] * 16 + 4) * 32 * 4 > 160 * 1024)
+                return fail(MZ_ERR_ARG, "mz_set_network_mfma: a layer's inputs for 32 trees exceed LDS");
+            for (int ct = 0; ct < st[9]; ct += MZ_LVL_WAVES) {
+                jobs.push_back(s); jobs.push_back(ct); jobs.push_back(std::min(MZ_LVL_WAVES, st[9] - ct));
+            }
+        }
+        job0.push_back((int)jobs.size() / 3);
+    }
+    for (int i = 0; i < n_tiles; i++)
+        if (steps_h[12 * tiles_h[2 * i]] < 0 || steps_h[12 * tiles_h[2 * i]] >= n_levels)
+            return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad level");
     for (void *&p : c->mnet_bufs) if (p) { (void)hipFree(p); p = nullptr; }
+    c->mnet_level_job0 = job0;
+    c->mnet_max_k16 = 1;
+    for (int s2 = 0; s2 < n_steps; s2++) c->mnet_max_k16 = std::max(c->mnet_max_k16, (int)steps_h[12 * s2 + 2]);
+    c->mnet_tile_fits = (size_t)stride * 16 * 4 <= 160 * 1024;
+    HIPCHK(hipMalloc(&c->mnet_bufs[5], jobs.size() * 4));
+    HIPCHK(hipMemcpy(c->mnet_bufs[5], jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice));
+    const size_t act_rows = ((size_t)c->cfg.max_batch + 31) / 32 * 32;
+    HIPCHK(hipMalloc(&c->mnet_bufs[6], act_rows * stride * 4));
+    HIPCHK(hipMemset(c->mnet_bufs[6], 0, act_rows * stride * 4));
     const void *src[5] = {steps_h, tiles_h, level_start_h, wfrag_h, bias_h};
     size_t n[5] = {(size_t)n_steps * 12, (size_t)n_tiles * 2, (size_t)n_levels + 1, (size_t)n_w, (size_t)n_b};
     for (int i = 0; i < 5; i++) {
@@ -788,14 +821,43 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
     if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no pending selection (call mz_select first)");
     if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no network uploaded (call mz_set_network_mfma first)");
     int leaf = c->n_expanded + 1;
-    // 32 trees per block while their activations fit in LDS, else 16
+    // 32 trees per block while their activations fit in LDS, else 16; batches that would leave most CUs
+    // without a tile (and networks whose tile does not fit at all) go level by level through global memory
     const int tm = (size_t)c->mnet.stride * 32 * 4 <= 160 * 1024 ? 32 : 16;
-    size_t lds = (size_t)c->mnet.stride * tm * 4;
-    auto kern = tm == 32 ? k_net_step<32> : k_net_step<16>;
-    // per launch, like the other kernels with large dynamic LDS: the attribute belongs to the current device
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream, c->d,
-                       c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
+    bool by_level = !c->mnet_tile_fits || (c->B + tm - 1) / tm < 128;
+    if (const char *e = getenv("MZ_NET_PATH")) by_level = !c->mnet_tile_fits || strcmp(e, "level") == 0;
+    if (by_level) {
+        float *acts = (float *)c->mnet_bufs[6];
+        const int32_t *jobs = (const int32_t *)c->mnet_bufs[5];
+        const unsigned tree_tiles = (unsigned)((c->B + 31) / 32);
+        const size_t lds = (size_t)(c->mnet_max_k16 * 16 + 4) * 32 * 4;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_level<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_level<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int l = 0; l < c->mnet.n_levels; l++) {
+            const int j0 = c->mnet_level_job0[l], nb = c->mnet_level_job0[l + 1] - j0;
+            if (nb < 1) continue;
+            if (l == 0)
+                hipLaunchKernelGGL(k_net_level<true>, dim3(nb, tree_tiles), dim3(MZ_LVL_WAVES * 64), lds, (hipStream_t)stream, c->d, c->mnet,
+                                   jobs + 3 * j0, acts);
+            else
+                hipLaunchKernelGGL(k_net_level<false>, dim3(nb, tree_tiles), dim3(MZ_LVL_WAVES * 64), lds, (hipStream_t)stream, c->d, c->mnet,
+                                   jobs + 3 * j0, acts);
+        }
+        // a whole wave per tree when the supports or the hidden state are long
+        if (c->mnet.io[9] > 64 || c->mnet.io[6] / c->mnet.io[10] > 64)
+            hipLaunchKernelGGL(k_net_epilogue<64>, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, c->d, c->mnet, leaf,
+                               (const float *)acts, c->leaf_logits, c->leaf_value, c->leaf_reward);
+        else
+            hipLaunchKernelGGL(k_net_epilogue<16>, dim3((c->B + 15) / 16), dim3(256), 0, (hipStream_t)stream, c->d, c->mnet, leaf,
+                               (const float *)acts, c->leaf_logits, c->leaf_value, c->leaf_reward);
+    } else {
+        size_t lds = (size_t)c->mnet.stride * tm * 4;
+        auto kern = tm == 32 ? k_net_step<32> : k_net_step<16>;
+        // per launch, like the other kernels with large dynamic LDS: the attribute belongs to the current device
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream, c->d,
+                           c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
+    }
     if ((rc = launch_status("mz_expand_backup_net"))) return rc;
     select_next = select_next && leaf < c->cfg.n_simulations;
     if (select_next) {

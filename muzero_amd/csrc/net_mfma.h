@@ -43,14 +43,18 @@ __device__ __forceinline__ float apply_act(float v, int act)
 // HALVES = 2: both 16-row halves of the tile from one pass over the weights (two accumulator chains);
 // HALVES = 1: only half `half` (finer jobs, used to even out levels whose tile count does not divide
 // by the number of waves).
+// Inputs are read from `in` (rows `in_stride` floats apart, the step's input at `in_off`), outputs and the
+// optional skip operand live in `out` (rows `out_stride` apart): the same array for a tile that is
+// resident in LDS, an LDS copy of the inputs and the global activation array for the per-level kernel.
 template <int HALVES>
-__device__ __forceinline__ void mfma_tile(const MfmaNet &net, float *act, const int32_t *st, int ct, int half, int lane)
+__device__ __forceinline__ void mfma_tile(const MfmaNet &net, const float *in, int in_stride, int in_off, float *out,
+                                          int out_stride, const int32_t *st, int ct, int half, int lane)
 {
-    const int N = st[1], k16n = st[2], in_off = st[3], out_off = st[4], skip_off = st[5], actf = st[6];
+    const int N = st[1], k16n = st[2], out_off = st[4], skip_off = st[5], actf = st[6];
     const float4 *wp = reinterpret_cast<const float4 *>(net.wfrag + st[7]) + (long long)ct * k16n * 64 + lane;
     const int row0 = HALVES == 2 ? 0 : half * 16;
-    const float *a0 = act + (row0 + (lane & 15)) * net.stride + in_off + (lane >> 4) * 4;
-    const float *a1 = a0 + 16 * net.stride;
+    const float *a0 = in + (row0 + (lane & 15)) * in_stride + in_off + (lane >> 4) * 4;
+    const float *a1 = a0 + 16 * in_stride;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     for (int k0 = 0; k0 < k16n; k0 += MZ_WPF) {
         float4 w[MZ_WPF];
@@ -81,7 +85,7 @@ __device__ __forceinline__ void mfma_tile(const MfmaNet &net, float *act, const 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             int r0 = row0 + (lane >> 4) * 4 + j;
-            float *o0 = act + r0 * net.stride, *o1 = o0 + 16 * net.stride;
+            float *o0 = out + (long long)r0 * out_stride, *o1 = o0 + 16 * (long long)out_stride;
             float v0 = acc0[j] + b;
             if (skip_off >= 0) v0 += o0[skip_off + col];
             o0[out_off + col] = apply_act(v0, actf);
@@ -133,7 +137,7 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, float *act, 
         if constexpr (TM == 16) {  // one 16-row block per column tile
             for (int ti = wave; ti < n_tiles; ti += NW) {
                 int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
-                mfma_tile<1>(net, act, net.steps + 12 * s, ct, 0, lane);
+                mfma_tile<1>(net, act, net.stride, net.steps[12 * s + 3], act, net.stride, net.steps + 12 * s, ct, 0, lane);
             }
             __syncthreads();
             continue;
@@ -142,27 +146,28 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, float *act, 
         const int n_whole = n_tiles / NW * NW;
         for (int ti = wave; ti < n_whole; ti += NW) {
             int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
-            mfma_tile<2>(net, act, net.steps + 12 * s, ct, 0, lane);
+            mfma_tile<2>(net, act, net.stride, net.steps[12 * s + 3], act, net.stride, net.steps + 12 * s, ct, 0, lane);
         }
         for (int j = wave; j < 2 * (n_tiles - n_whole); j += NW) {
             int ti = first + n_whole + (j >> 1);
             int s = net.tiles[2 * ti], ct = net.tiles[2 * ti + 1];
-            mfma_tile<1>(net, act, net.steps + 12 * s, ct, j & 1, lane);
+            mfma_tile<1>(net, act, net.stride, net.steps[12 * s + 3], act, net.stride, net.steps + 12 * s, ct, j & 1, lane);
         }
         __syncthreads();
     }
 }
 
-// Epilogue of one tree by its 16-lane group: next hidden state (per-group min-max scaling,
+// Epilogue of one tree by its group of LANES lanes: next hidden state (per-group min-max scaling,
 // utils/network_utils.py:132-158) into `hidden_dst`, value and reward (support_to_scalar,
 // utils/network_utils.py:75-96).  The policy logits stay in the tree's row at io[4].
+template <int LANES = 16>
 __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *row, int a, float *hidden_dst,
                                                double *value, double *reward)
 {
     const int H = net.io[6], sup = net.io[9], ngroups = net.io[10];
     const int per = H / ngroups;
     if (ngroups >= 8) {  // many small groups (board planes): one lane per group
-        for (int g = a; g < ngroups; g += 16) {
+        for (int g = a; g < ngroups; g += LANES) {
             const float *raw = row + net.io[2] + g * per;
             float mn = raw[0], mx = raw[0];
             for (int j = 1; j < per; j++) { float v = raw[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
@@ -170,9 +175,9 @@ __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *r
             for (int j = 0; j < per; j++) hidden_dst[g * per + j] = (raw[j] - mn) / den;
         }
     } else {
-        minmax_to<16>(row + net.io[2], H, ngroups, a, hidden_dst, nullptr);
+        minmax_to<LANES>(row + net.io[2], H, ngroups, a, hidden_dst, nullptr);
     }
-    support_to_scalar2<16>(row + net.io[5], row + net.io[3], sup, a, value, reward);
+    support_to_scalar2<LANES>(row + net.io[5], row + net.io[3], sup, a, value, reward);
 }
 
 // recurrent_inference (network.py:105-126) for every tree's pending selection, then nothing else:
@@ -201,6 +206,71 @@ __global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int le
     double value, reward;
     tile_epilogue(net, row, a, d.hidden + ((long long)t * d.L.N + leaf) * H, &value, &reward);
     for (int j = a; j < A; j += 16) out_logits[(long long)t * A + j] = row[net.io[4] + j];
+    if (a == 0) { out_value[t] = value; out_reward[t] = reward; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-level evaluation with the activations in global memory, for batches too small to fill the chip
+// with one tile of trees per block and for networks whose tile does not fit in LDS: the grid covers
+// (blocks of a few column tiles of one step) x (tiles of 32 trees), so a level of a wide network is
+// hundreds of blocks even for a thousand trees.  A block copies its step's input columns of its 32 trees
+// into LDS once; each wave then computes one column tile for all 32 trees.  Same k order per output as
+// the tile-resident kernels, hence the same results.
+// jobs: int32 [n_blocks][3] = (step, first column tile, number of column tiles <= MZ_LVL_WAVES).
+// FIRST: the level reads the network's inputs, which are taken straight from the trees (hidden state of
+// each tree's selected parent + encoded action, mcts/mcts.py:240-243) instead of `acts`.
+#define MZ_LVL_WAVES 8  // column tiles (= waves) per block of the per-level kernel
+template <bool FIRST>
+__global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level(Dev d, MfmaNet net, const int32_t *jobs, float *acts)
+{
+    constexpr int PT = MZ_LVL_WAVES * 64 / 32;  // threads that copy one tree's inputs
+    extern __shared__ __align__(16) float tile[];  // [32][ts]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *job = jobs + 3 * blockIdx.x;
+    const int32_t *st = net.steps + 12 * job[0];
+    const int KK = st[2] * 16, ts = KK + 4, in_off = st[3];
+    const int t0 = blockIdx.y * 32, i = tid / PT, part = tid % PT, t = t0 + i;
+    const int H = net.io[6], asz = net.io[8];
+    float *dst = tile + i * ts;
+    if constexpr (FIRST) {
+        int parent = 0, action = -1;
+        const bool live = t < d.B;
+        if (live) { parent = d.sel_parent[t]; action = d.sel_action[t]; }
+        const float *ph = d.hidden + ((long long)(live ? t : 0) * d.L.N + parent) * H;
+        const int rel = in_off - net.io[0];  // the step may read a view that starts inside the input tensor
+        for (int j = part; j < KK; j += PT) {
+            int e = j + rel;
+            float v = 0.0f;
+            if (live) v = e < H ? ph[e] : ((e - H == action && e < H + asz) ? 1.0f : 0.0f);
+            dst[j] = v;
+            // later levels may read the inputs too (residual skips): keep them in `acts` as well (the
+            // blocks of this level that share a tree tile write the same values)
+            if (e < H + asz) acts[(long long)t * net.stride + in_off + j] = v;
+        }
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(acts + (long long)t * net.stride + in_off);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int j = part; j < KK / 4; j += PT) d4[j] = src[j];   // rows past the batch exist in `acts` (zero)
+    }
+    __syncthreads();
+    if (wave < job[2])
+        mfma_tile<2>(net, tile, ts, 0, acts + (long long)t0 * net.stride, net.stride, st, job[1] + wave, 0, lane);
+}
+
+// Epilogue of the per-level path: one group of LANES (16 or 64) lanes per tree reads its row of `acts`.
+// The reductions are order-insensitive except for the float32 sums of the supports, whose order depends
+// on LANES: 16 gives the tile-resident kernels' results bit for bit, 64 is faster for long supports.
+template <int LANES>
+__global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int leaf, const float *acts, float *out_logits,
+                                                       double *out_value, double *out_reward)
+{
+    const int t = (int)(blockIdx.x * (256 / LANES) + threadIdx.x / LANES), a = threadIdx.x % LANES;
+    if (t >= d.B) return;
+    const int H = net.io[6], A = net.io[7];
+    const float *row = acts + (long long)t * net.stride;
+    double value, reward;
+    tile_epilogue<LANES>(net, row, a, d.hidden + ((long long)t * d.L.N + leaf) * H, &value, &reward);
+    for (int j = a; j < A; j += LANES) out_logits[(long long)t * A + j] = row[net.io[4] + j];
     if (a == 0) { out_value[t] = value; out_reward[t] = reward; }
 }
 

@@ -142,7 +142,7 @@ def test_network_too_large_for_lds_is_rejected():
 
 @pytest.mark.parametrize('name,B', [('resnet_tictactoe', 100), ('mlp_synthetic', 77), ('mlp_cartpole', 33),
                                     ('mlp_wide256', 40)])
-def test_mfma_leaf_evaluation_matches_torch_network(name, B):
+def test_mfma_leaf_evaluation_matches_torch_network(name, B, monkeypatch):
     """Leaves evaluated by the matrix-core kernel vs the same lowered network run by torch:
     first-simulation outputs within 1e-5 (hidden 1e-4), whole searches agree tree by tree."""
     from muzero_amd.engine import SearchEngine
@@ -170,7 +170,9 @@ def test_mfma_leaf_evaluation_matches_torch_network(name, B):
     g = rng.gumbel(size=(B, A)) if gumbel else None
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     results = []
-    for mode in ('mfma', 'mfma_fused', 'mfma_search', 'torch'):
+    for mode in ('mfma', 'mfma_fused', 'mfma_search', 'mfma_level', 'torch'):
+        # 'mfma_level': layer by layer with the activations in global memory (what small batches use)
+        monkeypatch.setenv('MZ_NET_PATH', 'level' if mode == 'mfma_level' else 'tile')
         eng = SearchEngine(cfg, net.H, B, seed=2)
         eng.set_network_mfma(pm, io)
         prior = eng.root_prepare(logits, legal, di, 0.25)
@@ -188,9 +190,9 @@ def test_mfma_leaf_evaluation_matches_torch_network(name, B):
                 eng.select(want_hidden=False)
                 for sim in range(S):
                     eng.expand_backup_net(select_next=True)
-        for sim in range(S if mode in ('mfma', 'torch') else 0):
+        for sim in range(S if mode in ('mfma', 'mfma_level', 'torch') else 0):
             parent, action, phid = eng.select()
-            if mode == 'mfma':
+            if mode in ('mfma', 'mfma_level'):
                 if sim == 0:
                     lg, nh, val, rew = gnet.recurrent_flat(phid, gnet.encode_actions(action))
                 eng.expand_backup_net()
@@ -208,8 +210,13 @@ def test_mfma_leaf_evaluation_matches_torch_network(name, B):
         a, v, p, _ = eng.to_act(0.0)
         results.append((a.cpu().numpy().copy(), v.cpu().numpy().copy()))
         eng.close()
-    for k in (1, 2):   # fewer launches, the very same search
+    for k in (1, 2, 3):   # fewer launches / other data placement, the very same search
+        if k == 3 and name == 'mlp_wide256':
+            # long supports are reduced by 64 lanes instead of 16 on this path: float32 sums in another order
+            assert (results[0][0] == results[k][0]).mean() >= 0.97
+            assert (np.abs(results[0][1] - results[k][1]) < 1e-5).mean() >= 0.97
+            continue
         np.testing.assert_array_equal(results[0][0], results[k][0])
         np.testing.assert_array_equal(results[0][1], results[k][1])
-    assert (results[0][0] == results[3][0]).mean() >= 0.97
-    assert (np.abs(results[0][1] - results[3][1]) < 1e-5).mean() >= 0.97
+    assert (results[0][0] == results[4][0]).mean() >= 0.97
+    assert (np.abs(results[0][1] - results[4][1]) < 1e-5).mean() >= 0.97
