@@ -292,3 +292,47 @@ def test_result_is_independent_of_the_shard_layout():
         parts = [run(*shard_range(B, r, world)) for r in range(world)]
         for k in range(5):
             np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), whole[k])
+
+
+def test_random_configurations_vs_checker():
+    """Forty random search configurations (rule, action count, simulations, players, discount, legality,
+    group width, hash-network shape): whole batches against the CPU checker, bit for bit."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        gumbel = bool(rng.integers(2))
+        A = int(rng.choice([2, 3, 4, 6, 7, 9, 12, 16, 18, 25, 40, 64]))
+        S = int(rng.integers(1, 60))
+        players = int(rng.integers(1, 3))
+        gamma = float(rng.choice([1.0, 0.997, 0.9]))
+        H = int(rng.integers(2, 9))
+        B = int(rng.integers(1, 70))
+        cfg = make_config(gumbel, A, S, players, gamma)
+        if gumbel:
+            cfg.max_considered_actions = int(rng.choice([2, 4, 16]))
+        hp = hashnet.HashNetParams(A, H, int(rng.integers(2, 7)), int(rng.integers(2)), int(rng.integers(2)))
+        codes, legal = _batch_inputs(A, B, rng, partial=bool(rng.integers(2)))
+        to_play = rng.integers(0, players, size=B).astype(np.int32)
+        gnoise = rng.gumbel(size=(B, A)) if gumbel else None
+        dirichlet = None if gumbel else rng.dirichlet([0.25] * A, size=B)
+        ref = orc.search_batch_hash(cfg, hp, H, codes, legal, to_play, dirichlet=dirichlet, frac=0.25, gumbel=gnoise,
+                                    seed=trial, tree_id0=trial * 7, n_threads=4)
+        rl = 2
+        while rl < A:
+            rl *= 2
+        lanes = int(rng.choice(sorted({rl, max(rl, 16), 64})))
+        eng = _engine(cfg, H, B, seed=trial, lanes_per_tree=lanes)
+        logits = np.stack([hashnet.logits_of(int(c), hp) for c in codes])
+        prior = eng.root_prepare(logits, legal, dirichlet, 0.25)
+        eng.reset(prior, [hashnet.value_of(int(c)) for c in codes],
+                  np.stack([hashnet.hidden_of(int(c), hp) for c in codes]), to_play, legal, gnoise, tree_id0=trial * 7)
+        eng.search_hash(hp.logit_shift, hp.reward_on, hp.parent_predicts)
+        action, value, probs, _ = eng.to_act(0.0)
+        nv, _ = eng.stats()
+        tag = (trial, gumbel, A, S, players, gamma, lanes)
+        assert np.array_equal(nv.cpu().numpy(), ref.node_visits), tag
+        assert np.array_equal(value.cpu().numpy(), ref.root_value), tag
+        assert np.array_equal(action.cpu().numpy(), ref.action), tag
+        for b in range(0, B, 9):
+            assert np.array_equal(eng.export_tree(b)['children_visits'][0], ref.root_visits[b]), tag
+        eng.close()
