@@ -1,6 +1,6 @@
 """Benchmark of the batched MCTS search (BASELINE.json metric: MCTS simulations/sec).
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3h|cfg4s|cfg5h]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3h|cfg3t|cfg4|cfg4s|cfg5|cfg5h|cfg5t]
 
 One process per GPU (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE).  A step is one full batched
 search over the rank's trees with inputs resident in HBM: root inference + root preparation

@@ -228,6 +228,34 @@ __device__ __forceinline__ void dense_run_cached(const DenseRegs<MAXL, MAXK4> &c
     }
 }
 
+// Whole-wave epilogue for small networks (one normalisation group of at most 16 hidden values, supports
+// of at most 32 bins): the hidden-state scaling of minmax_to and both support_to_scalar chains of
+// support_to_scalar2 in one branch-free stretch, so that the independent reduction chains interleave.
+// Same operations per value as the two functions it replaces.
+__device__ __forceinline__ void epilogue_wave_small(const float *raw, int H, const float *lgA, const float *lgB,
+                                                    int n, int a, float *hid_dst, double *outA, double *outB)
+{
+    const float inf = __builtin_huge_valf();
+    const bool up = a >= 32, has_h = a < H;
+    const int i = a & 31, L = (n - 1) / 2;
+    float v = i < n ? (up ? lgB : lgA)[i] : -inf;
+    float r = has_h ? raw[a] : 0.0f;
+    int W = 2;
+    while (W < H) W <<= 1;
+    float mn = gminf<16>(has_h ? r : inf, W), mx = gmaxf<16>(has_h ? r : -inf, W);
+    float m = half_reduce(v, -inf, up, [](float x, float y) { return y > x ? y : x; });
+    float den = (mx - mn) + 1e-5f;
+    float e = i < n ? expf(v - m) : 0.0f;
+    float hv = (r - mn) / den;
+    float sum = half_reduce(e, 0.0f, up, [](float x, float y) { return x + y; });
+    if (has_h) hid_dst[a] = hv;
+    double x = i < n ? (double)(e / sum) * (double)(i - L) : 0.0;
+    x = half_reduce(x, 0.0, up, [](double p, double q) { return p + q; });
+    double y = inv_value_transform(x);
+    *outA = wave_lane(y, 0);
+    *outB = wave_lane(y, 32);
+}
+
 // utils/network_utils.py:132-158: per-group min-max scaling of `raw` (LDS) into `dst` (and `dst2` if given).
 template <int LANES>
 __device__ __forceinline__ void minmax_to(const float *raw, int H, int ngroups, int a, float *dst, float *dst2)

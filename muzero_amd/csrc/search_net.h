@@ -119,6 +119,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
     long long visited = 0;
     const int asz = net.io[8], sup = net.io[9], ngroups = net.io[10];
+    const bool small_epilogue = ngroups == 1 && H <= 16 && sup <= 32;
     constexpr bool CAN_CACHE = LANES == 64;
     DenseRegs<2, 4> regs;
     bool cached = false;
@@ -150,10 +151,16 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         if (CAN_CACHE && cached) dense_run_cached<2, 4>(regs, sc);
         else dense_run<LANES>(meta, w, sc, a);
         MZ_STAMP(st_net)
-        minmax_to<LANES>(sc + net.io[2], H, ngroups, a, hid + (long long)leaf * H, nullptr);
-        MZ_STAMP(st_mm)
         double value, reward;
-        support_to_scalar2<LANES>(sc + net.io[5], sc + net.io[3], sup, a, &value, &reward);
+        if (LANES == 64 && small_epilogue) {
+            epilogue_wave_small(sc + net.io[2], H, sc + net.io[5], sc + net.io[3], sup, a, hid + (long long)leaf * H,
+                                &value, &reward);
+            MZ_STAMP(st_mm)
+        } else {
+            minmax_to<LANES>(sc + net.io[2], H, ngroups, a, hid + (long long)leaf * H, nullptr);
+            MZ_STAMP(st_mm)
+            support_to_scalar2<LANES>(sc + net.io[5], sc + net.io[3], sup, a, &value, &reward);
+        }
         float lg = on ? sc[net.io[4] + a] : 0.0f;
         MZ_STAMP(st_epi)
         expand_backup<LANES, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
