@@ -15,13 +15,15 @@ namespace mz {
 // One node = one contiguous record (64-byte aligned):
 //   header (32 B): i32 node_visits, parent, action_from_parent, to_play; f64 node_value, node_raw_value
 //   rows over actions: f64 children_values[A], f64 children_rewards[A],
-//                      prior[A] (f64 for PUCT, f32 for Gumbel), i32 children_visits[A], i32 children_index[A]
+//                      prior[A] (f64 for PUCT, f32 for Gumbel), children_visits[A], children_index[A]
+//                      (both i32, or i16 when N < 32768 and the narrower rows save a 64-byte unit)
 // Records of a tree are contiguous ([N] of them), trees are contiguous ([B]).
 struct Layout {
     int A, N, H, S;
     int rec;  // bytes per node record
     int off_cval, off_crew, off_prior, off_cvis, off_cidx;
     int prior_f32;
+    int idx16;  // children_visits / children_index rows stored as int16 (when that shortens the record)
     long long tree_stride;  // N * rec
 };
 

@@ -136,8 +136,13 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     L.off_crew = L.off_cval + 8 * A;
     L.off_prior = L.off_crew + 8 * A;
     L.off_cvis = L.off_prior + round_up((cfg->gumbel ? 4 : 8) * A, 8);
-    L.off_cidx = L.off_cvis + 4 * A;
-    L.rec = round_up(L.off_cidx + 4 * A, 64);
+    // visit counts and node indices fit int16 for N < 32768; the narrow rows are used when they shorten the
+    // 64-byte-granular record (A = 9 Gumbel: 320 -> 256 bytes, two full 128-byte lines instead of three)
+    L.idx16 = L.N < 32768 && round_up(L.off_cvis + round_up(2 * A, 4) + 2 * A, 64) < round_up(L.off_cvis + 8 * A, 64);
+    if (const char *e = getenv("MZ_IDX16")) L.idx16 = L.idx16 && atoi(e) != 0;
+    const int isz = L.idx16 ? 2 : 4;
+    L.off_cidx = L.off_cvis + round_up(isz * A, 4);
+    L.rec = round_up(L.off_cidx + isz * A, 64);
     L.tree_stride = (long long)L.N * L.rec;
     const size_t B = (size_t)cfg->max_batch;
     int rc = MZ_OK;
@@ -516,8 +521,15 @@ extern "C" int mz_tree_export(mz_ctx *c, int32_t b, mz_tree_host *o, void *strea
             if (live) {
                 memcpy(&o->children_values[k], r + L.off_cval + 8 * a, 8);
                 memcpy(&o->children_rewards[k], r + L.off_crew + 8 * a, 8);
-                memcpy(&o->children_visits[k], r + L.off_cvis + 4 * a, 4);
-                memcpy(&o->children_index[k], r + L.off_cidx + 4 * a, 4);
+                if (L.idx16) {
+                    int16_t v16, i16;
+                    memcpy(&v16, r + L.off_cvis + 2 * a, 2);
+                    memcpy(&i16, r + L.off_cidx + 2 * a, 2);
+                    o->children_visits[k] = v16; o->children_index[k] = i16;
+                } else {
+                    memcpy(&o->children_visits[k], r + L.off_cvis + 4 * a, 4);
+                    memcpy(&o->children_index[k], r + L.off_cidx + 4 * a, 4);
+                }
                 if (L.prior_f32) memcpy((float *)o->children_prior_logits + k, r + L.off_prior + 4 * a, 4);
                 else memcpy((double *)o->children_prior_logits + k, r + L.off_prior + 8 * a, 8);
             } else {
@@ -555,8 +567,14 @@ extern "C" int mz_tree_import(mz_ctx *c, int32_t b, const mz_tree_host *in, cons
             size_t k = (size_t)n * A + a;
             memcpy(r + L.off_cval + 8 * a, &in->children_values[k], 8);
             memcpy(r + L.off_crew + 8 * a, &in->children_rewards[k], 8);
-            memcpy(r + L.off_cvis + 4 * a, &in->children_visits[k], 4);
-            memcpy(r + L.off_cidx + 4 * a, &in->children_index[k], 4);
+            if (L.idx16) {
+                int16_t v16 = (int16_t)in->children_visits[k], i16 = (int16_t)in->children_index[k];
+                memcpy(r + L.off_cvis + 2 * a, &v16, 2);
+                memcpy(r + L.off_cidx + 2 * a, &i16, 2);
+            } else {
+                memcpy(r + L.off_cvis + 4 * a, &in->children_visits[k], 4);
+                memcpy(r + L.off_cidx + 4 * a, &in->children_index[k], 4);
+            }
             if (L.prior_f32) memcpy(r + L.off_prior + 4 * a, (const float *)in->children_prior_logits + k, 4);
             else memcpy(r + L.off_prior + 8 * a, (const double *)in->children_prior_logits + k, 8);
         }

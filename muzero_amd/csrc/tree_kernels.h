@@ -62,7 +62,7 @@ __device__ __forceinline__ void write_root(const Dev &d, int t, int a, bool on, 
     int sh = (int)((threadIdx.x % 64) / LANES) * LANES;  // this group's lanes inside the 64-bit ballot
     if constexpr (LANES < 64) mask = (mask >> sh) & ((1ull << LANES) - 1ull);
     if (on) {
-        w.cval[a] = 0.0; w.crew[a] = 0.0; w.cvis[a] = 0; w.cidx[a] = -1;
+        w.cval[a] = 0.0; w.crew[a] = 0.0; w.cvis.set(a, 0); w.cidx.set(a, -1);
         if (GUMBEL) {
             reinterpret_cast<float *>(w.prior)[a] = (float)prior;
             d.gumbel[(long long)t * d.L.A + a] = gumbel_a;
@@ -382,7 +382,7 @@ __global__ void k_node_backward(Dev d, int t, int leaf, int to_play)
         pw.hdr->value = (pw.hdr->value * (double)pv + sv) / (double)(pv + 1);
         pw.hdr->visits = pv + 1;
         pw.cval[a] = lf.hdr->value;
-        pw.cvis[a] += 1;
+        pw.cvis.set(a, pw.cvis.get(a) + 1);
         leaf_value = reward + d.discount * leaf_value;
         leaf = p;
     }

@@ -6,11 +6,26 @@
 
 namespace mz {
 
+// A row of small integers (visit counts, node indices) stored as int32 or int16.
+struct IntRow {
+    char *p;
+    bool i16;
+    __device__ __forceinline__ int get(int a) const
+    {
+        return i16 ? (int)reinterpret_cast<const int16_t *>(p)[a] : reinterpret_cast<const int32_t *>(p)[a];
+    }
+    __device__ __forceinline__ void set(int a, int v) const
+    {
+        if (i16) reinterpret_cast<int16_t *>(p)[a] = (int16_t)v;
+        else reinterpret_cast<int32_t *>(p)[a] = v;
+    }
+};
+
 struct RowView {
     NodeHdr *hdr;
     double *cval, *crew;
     void *prior;
-    int32_t *cvis, *cidx;
+    IntRow cvis, cidx;
 };
 
 __device__ __forceinline__ RowView view(const Dev &d, const TreeMem &m, int n)
@@ -21,8 +36,8 @@ __device__ __forceinline__ RowView view(const Dev &d, const TreeMem &m, int n)
     v.cval = reinterpret_cast<double *>(r + d.L.off_cval);
     v.crew = reinterpret_cast<double *>(r + d.L.off_crew);
     v.prior = r + d.L.off_prior;
-    v.cvis = reinterpret_cast<int32_t *>(r + d.L.off_cvis);
-    v.cidx = reinterpret_cast<int32_t *>(r + d.L.off_cidx);
+    v.cvis = IntRow{r + d.L.off_cvis, d.L.idx16 != 0};
+    v.cidx = IntRow{r + d.L.off_cidx, d.L.idx16 != 0};
     return v;
 }
 
@@ -44,8 +59,8 @@ __device__ __forceinline__ NodeStats load_node(const Dev &d, const TreeMem &m, i
     s.raw = w.hdr->raw;
     s.cv = 0; s.ci = -1; s.prior = 0; s.r = 0; s.v = 0;
     if (on) {
-        s.cv = w.cvis[a];
-        s.ci = w.cidx[a];
+        s.cv = w.cvis.get(a);
+        s.ci = w.cidx.get(a);
         s.prior = GUMBEL ? (double)reinterpret_cast<float *>(w.prior)[a]
                          : reinterpret_cast<double *>(w.prior)[a];
         s.r = w.crew[a];
@@ -292,11 +307,11 @@ __device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, in
         *lf.hdr = h;
         if (m.depth) m.depth[leaf] = depth;
         RowView pr = view(d, m, parent);
-        pr.cidx[action] = leaf;
+        pr.cidx.set(action, leaf);
         pr.crew[action] = reward;
     }
     if (on) {
-        lf.cval[a] = 0.0; lf.crew[a] = 0.0; lf.cvis[a] = 0; lf.cidx[a] = -1;
+        lf.cval[a] = 0.0; lf.crew[a] = 0.0; lf.cvis.set(a, 0); lf.cidx.set(a, -1);
         if (GUMBEL) reinterpret_cast<float *>(lf.prior)[a] = logit;
         else reinterpret_cast<double *>(lf.prior)[a] = (double)logit;
     }
@@ -317,7 +332,7 @@ __device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, in
             pw = view(d, m, p);
             nv = pw.hdr->visits; V = pw.hdr->value; tp = pw.hdr->to_play;
             r = i == 0 ? reward : pw.crew[pa];
-            cvs = pw.cvis[pa];
+            cvs = pw.cvis.get(pa);
         }
         int cnt = depth - base < LANES ? depth - base : LANES;
         lds_r[a] = r;
@@ -353,7 +368,7 @@ __device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, in
             pw.hdr->visits = nv + 1;
             pw.hdr->value = newV;
             pw.cval[pa] = child_new;
-            pw.cvis[pa] = cvs + 1;
+            pw.cvis.set(pa, cvs + 1);
         }
     }
 }
