@@ -257,7 +257,10 @@ def main():
                                 'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg},
+                     'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
+                     'limiter': 'not HBM: the shader-sequencer counters (profiles/round1_final_sq_counters.txt) show the '
+                                'large-batch tree kernels at ~80% of the VALU issue rate and the 256-tree search waiting on '
+                                'dependent-instruction and LDS latency of one wave per tree'},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
