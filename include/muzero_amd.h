@@ -260,6 +260,11 @@ int mz_make_targets(const mz_trajectories *traj_h, int32_t n_samples, const int3
                     const double *gamma_pow, int32_t n_stack, int32_t stack_action, float *out_obs,
                     float *out_actions, float *out_value, float *out_reward, float *out_policy, void *stream);
 
+/* scalar_to_support with the default value transform (utils/network_utils.py:70-71, 99-129), which the
+ * trainer applies to the value and reward targets (trainer.py:70-71): x f32[n] -> out f32[n][2L+1].
+ * Device pointers; needs no context. */
+int mz_scalar_to_support(const float *x, int64_t n, int32_t support_limit, float *out, void *stream);
+
 /* Sequential-halving schedule, mcts/action_selection.py:160-175 (host, pure integer). out_h i32[S]. */
 int mz_considered_visits(int32_t max_considered_actions, int32_t simulations, int32_t *out_h);
 

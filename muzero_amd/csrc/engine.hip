@@ -468,6 +468,16 @@ extern "C" int mz_make_targets(const mz_trajectories *tr, int32_t n_samples, con
     return launch_status("mz_make_targets");
 }
 
+extern "C" int mz_scalar_to_support(const float *x, int64_t n, int32_t support_limit, float *out, void *stream)
+{
+    (void)hipGetLastError();
+    if (!x || !out || n < 1 || support_limit < 1) return fail(MZ_ERR_ARG, "mz_scalar_to_support: null/empty argument");
+    const long long total = (long long)n * (2 * support_limit + 1);
+    hipLaunchKernelGGL(k_scalar_to_support, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)n, (int)support_limit, out);
+    return launch_status("mz_scalar_to_support");
+}
+
 extern "C" int mz_stats(mz_ctx *c, int64_t *out_node_visits, int32_t *out_noise_calls, void *stream)
 {
     int rc = check_ctx(c, "mz_stats");

@@ -97,4 +97,27 @@ __global__ void k_make_targets(TrajDev tr, int n_samples, const int32_t *game_id
     }
 }
 
+// utils/network_utils.py:70-71 + 99-129 (scalar_to_support with the default transform): float32
+// h(x) = sign(x) (sqrt(|x| + 1) - 1) + 0.001 x, clamped to [-L, L], spread over the two neighbouring
+// integer bins.  One thread per output element: out[i][j], j = 0 .. 2L.
+__global__ void k_scalar_to_support(const float *x, long long n, int L, float *out)
+{
+    const int bins = 2 * L + 1;
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * bins) return;
+    const long long i = gid / bins;
+    const int j = (int)(gid % bins);
+    float v = x[i];
+    float sg = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+    float h = sg * (sqrtf(fabsf(v) + 1.0f) - 1.0f) + 0.001f * v;
+    h = fminf(fmaxf(h, (float)-L), (float)L);
+    float fl = floorf(h);
+    float prob = h - fl;
+    int lo = (int)fl + L;
+    float r = 0.0f;
+    if (j == lo) r = 1.0f - prob;
+    else if (j == lo + 1) r = prob;   // lo + 1 > 2L only when prob == 0: nothing to write
+    out[gid] = r;
+}
+
 }  // namespace mz

@@ -51,7 +51,7 @@ ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
            'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
-           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets',
+           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
 

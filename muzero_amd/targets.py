@@ -25,6 +25,18 @@ class MzTrajectories(C.Structure):
                 ('re_root_values', C.c_void_p), ('re_probs', C.c_void_p), ('has_reanalysed', C.c_void_p)]
 
 
+def scalar_to_support(x: torch.Tensor, support_limit: int) -> torch.Tensor:
+    """Categorical form of value / reward targets, as the trainer builds it (trainer.py:70-71 ->
+    utils/network_utils.py:99-129): float32 device tensor (...,) -> (..., 2 * support_limit + 1)."""
+    if not x.is_cuda:
+        raise _engine.EngineError('scalar_to_support needs a device tensor (there is no CPU fallback)')
+    xf = x.to(torch.float32).contiguous()
+    out = torch.empty(tuple(xf.shape) + (2 * int(support_limit) + 1,), dtype=torch.float32, device=x.device)
+    _check(lib().mz_scalar_to_support(_ptr(xf), C.c_int64(xf.numel()), C.c_int32(int(support_limit)), _ptr(out), _stream()),
+           'mz_scalar_to_support')
+    return out
+
+
 class TrajectoryStore:
     """Flat device copy of a list of finished games (objects with the `GameHistory` fields)."""
 

@@ -949,3 +949,27 @@ void orc_stack_observations(int T, int obs, const double *observations, const in
     for (int r = 0; r < (n - n_) * (stack_action ? 2 : 1); r++, row++)
         for (int i = 0; i < obs; i++) out[row * obs + i] = 0.0;
 }
+
+/* scalar_to_support with the default transform (utils/network_utils.py:70-71, 99-129), float32 like the
+ * torch expressions: out[i][0 .. 2L] for each of the n scalars. */
+void orc_scalar_to_support(const float *x, int64_t n, int L, float *out)
+{
+    const int bins = 2 * L + 1;
+    for (int64_t i = 0; i < n; i++) {
+        float v = x[i];
+        float sg = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+        float root = sqrtf(fabsf(v) + 1.0f) - 1.0f;
+        float scaled = sg * root;
+        float eps_x = 0.001f * v;
+        float h = scaled + eps_x;
+        if (h < (float)-L) h = (float)-L;
+        if (h > (float)L) h = (float)L;
+        float fl = floorf(h);
+        float prob = h - fl;
+        int lo = (int)fl + L, hi = lo + 1;
+        for (int j = 0; j < bins; j++) out[i * bins + j] = 0.0f;
+        out[i * bins + lo] = 1.0f - prob;                    /* first scatter_ */
+        if (hi > 2 * L) { prob = 0.0f; hi = 0; }             /* masked_fill_ of both tensors */
+        out[i * bins + hi] = prob;                           /* second scatter_ */
+    }
+}

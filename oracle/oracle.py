@@ -311,3 +311,13 @@ def stack_observations(observations, actions, t, n, n_actions, stack_action):
     f(C.c_int(T), C.c_int(flat.shape[1]), _p(flat), _p(act), C.c_int(int(t)), C.c_int(int(n)), C.c_int(int(n_actions)),
       C.c_int(int(bool(stack_action))), _p(out))
     return out
+
+
+def scalar_to_support(x, support_limit):
+    """utils/network_utils.scalar_to_support on a float32 array -> (..., 2L+1) float32."""
+    xf = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(xf.shape + (2 * int(support_limit) + 1,), np.float32)
+    f = lib().orc_scalar_to_support
+    f.restype = None
+    f(_p(xf), C.c_int64(xf.size), C.c_int(int(support_limit)), _p(out))
+    return out

@@ -662,6 +662,11 @@ def gen_targets():
         names = ('obs', 'actions', 'value', 'reward', 'policy')
         for k, n in enumerate(names):   # ftensor(np.asarray(.)): float32 tensors
             out[p + 'batch_' + n] = torch.as_tensor(np.asarray(batch[k]), dtype=torch.float32).numpy()
+        # what the trainer does first with the value / reward targets (trainer.py:70-71)
+        L = 10 if ci % 2 == 0 else 300
+        out[p + 'support_limit'] = np.int64(L)
+        for n in ('value', 'reward'):
+            out[p + n + '_support'] = ref_nu.scalar_to_support(torch.as_tensor(out[p + 'batch_' + n]), L).numpy()
         ci += 1
     out['n_cases'] = np.int64(ci)
     np.savez_compressed(os.path.join(HERE, 'targets.npz'), **out)

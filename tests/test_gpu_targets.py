@@ -30,6 +30,11 @@ def test_device_batches_equal_reference_batches():
         np.testing.assert_array_equal(obs.cpu().numpy().reshape(Bs, -1), z[p + 'batch_obs'].reshape(Bs, -1))
         np.testing.assert_array_equal(act.cpu().numpy().reshape(Bs, unroll + 1, -1),
                                       z[p + 'batch_actions'].reshape(Bs, unroll + 1, -1))
+        # categorical targets as the trainer builds them from the batch
+        from muzero_amd.targets import scalar_to_support
+        L = int(z[p + 'support_limit'])
+        np.testing.assert_array_equal(scalar_to_support(val, L).cpu().numpy(), z[p + 'value_support'])
+        np.testing.assert_array_equal(scalar_to_support(rew, L).cpu().numpy(), z[p + 'reward_support'])
         # sampling consumes np.random exactly like ReplayBuffer.sample
         np.random.seed(11 + ci)
         obs2, act2, val2, rew2, pol2 = store.sample(Bs, td, gamma, unroll)

@@ -78,3 +78,17 @@ def test_stacking_with_action_planes_matches_host_mirror():
             want = h.stack_n_observations(t, n, A, True)
             got = orc.stack_observations(d['observations'], d['actions'], t, n, A, True)
             np.testing.assert_array_equal(got.reshape(want.shape), want)
+
+
+def test_scalar_to_support_matches_reference():
+    z = np.load(os.path.join(GOLD, 'targets.npz'))
+    for ci in range(int(z['n_cases'])):
+        p = f'c{ci}_'
+        L = int(z[p + 'support_limit'])
+        for n in ('value', 'reward'):
+            np.testing.assert_array_equal(orc.scalar_to_support(z[p + 'batch_' + n], L), z[p + n + '_support'])
+    # clamping at both ends and exact integers
+    x = np.array([1e9, -1e9, 0.0, 3.0, -3.0], np.float32)
+    out = orc.scalar_to_support(x, 2)
+    assert out[0].tolist() == [0, 0, 0, 0, 1] and out[1].tolist() == [1, 0, 0, 0, 0] and out[2].tolist() == [0, 0, 1, 0, 0]
+    np.testing.assert_allclose(out.sum(-1), 1.0, rtol=0, atol=1e-6)
