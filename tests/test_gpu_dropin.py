@@ -213,3 +213,33 @@ def test_reference_style_module_is_lowered_once_per_weight_version(mcts_pkg):
     a3, v3, p3 = search.search_batch(mod, obs, np.ones((4, 2)), np.zeros(4, np.int32))
     assert search._lowered[id(mod)][1] is not low1
     assert not np.array_equal(v3, v1)
+
+
+@pytest.mark.parametrize('name,obs_shape', [('mlp_cartpole', (1, 1, 4)), ('resnet_tictactoe', (3, 3, 3))])
+def test_single_search_with_stream_noise_same_on_every_path(mcts_pkg, monkeypatch, name, obs_shape):
+    """MCTS.search (PUCT, tie-break rows taken from the global NumPy stream) with a lowered network: the
+    single-launch paths and the select / torch network / expand loop consume the same draws and agree."""
+    m = mcts_pkg[0]
+    from test_network_lowering import load_net
+    z, net = load_net(name)
+    net.to('cuda')
+    A = net.A
+    cfg = make_config(False, A, 20, 2 if A == 9 else 1, 1 if A == 9 else 0.997)
+    obs = np.asarray(z['obs'][0], dtype=np.float64).reshape(obs_shape)
+    legal = np.ones(A)
+    enc = lambda a: np.eye(A)[a]  # noqa: E731
+    agree = 0
+    for seed in range(6):
+        out = []
+        for one_launch in (True, False):
+            search = m.MCTS(cfg)
+            if not one_launch:
+                monkeypatch.setattr(m.MCTS, '_lowered_plan', staticmethod(lambda network, A: None))
+            np.random.seed(seed)
+            a, v, p = search.search(net, obs, legal, enc, 0, 1.0)
+            out.append((int(a), float(v), np.asarray(p), np.random.random_sample()))
+            monkeypatch.undo()
+        assert abs(out[0][1] - out[1][1]) < 1e-5
+        np.testing.assert_allclose(out[0][2], out[1][2], atol=1e-6)
+        agree += out[0][0] == out[1][0] and out[0][3] == out[1][3]   # same action, stream left at the same place
+    assert agree >= 5
