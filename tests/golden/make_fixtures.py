@@ -673,8 +673,75 @@ def gen_targets():
     print('targets.npz', ci, 'cases')
 
 
+def gen_trainer():
+    """Three optimisation steps as Trainer.update_weights / update_weights_continuously perform them
+    (trainer.py:43-45, 62-123; the actor itself needs ray), spelled out with the reference's own
+    scalar_to_support / scale_gradient / update_lr on a small stand-in network (tests/tiny_net.py)."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from tiny_net import TinyNet
+    out = {}
+    for ci, (optimizer, A, L, U) in enumerate((('Adam', 2, 10, 5), ('SGD', 3, 4, 3))):
+        cfg = SimpleNamespace(lr=0.007, lr_decay_rate=0.9, lr_decay_steps=10, weight_decay=1e-4, momentum=0.9,
+                              support_limit=L, value_loss_weight=0.25, optimizer=optimizer)
+        rng = np.random.default_rng(40 + ci)
+        Bs = 12
+        net = TinyNet(4, A, 8, L, seed=ci)
+        net.train()
+        out[f'c{ci}_meta'] = np.array([A, L, U, Bs, optimizer == 'Adam'], dtype=np.int64)
+        for k, v in net.state_dict().items():
+            out[f'c{ci}_w0_{k}'] = v.numpy().copy()
+        if optimizer == 'Adam':
+            opt = torch.optim.Adam(net.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+        else:
+            opt = torch.optim.SGD(net.parameters(), lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+        losses = []
+        for step in range(3):
+            obs = torch.as_tensor(rng.normal(size=(Bs, 1, 1, 4)), dtype=torch.float32)
+            acts = torch.as_tensor(np.eye(A)[rng.integers(0, A, size=(Bs, U + 1))], dtype=torch.float32)
+            vt = torch.as_tensor(rng.normal(size=(Bs, U + 1)) * 3, dtype=torch.float32)
+            rt = torch.as_tensor(rng.integers(0, 3, size=(Bs, U + 1)) * 0.5, dtype=torch.float32)
+            pt = torch.as_tensor(rng.dirichlet([0.5] * A, size=(Bs, U + 1)), dtype=torch.float32)
+            for n, x in (('obs', obs), ('acts', acts), ('vt', vt), ('rt', rt), ('pt', pt)):
+                out[f'c{ci}_s{step}_{n}'] = x.numpy().copy()
+            ref_nu.update_lr(cfg.lr, cfg.lr_decay_rate, cfg.lr_decay_steps, step, opt)
+            vtb = ref_nu.scalar_to_support(vt, L)
+            rtb = ref_nu.scalar_to_support(rt, L)
+            policy_logits, hidden, value_logits = net.initial_inference(obs, False)
+            predictions = [(1.0, value_logits, torch.zeros_like(value_logits, requires_grad=True), policy_logits)]
+            for k in range(1, acts.shape[1]):
+                policy_logits, hidden, value_logits, reward_logits = net.recurrent_inference(hidden, acts[:, k], False)
+                ref_nu.scale_gradient(hidden, 0.5)
+                predictions.append((1.0 / acts.shape[1], value_logits, reward_logits, policy_logits))
+            value_loss, reward_loss, policy_loss = 0, 0, 0
+            f = torch.nn.CrossEntropyLoss()
+            for k, (scale, vl, rl, pl) in enumerate(predictions):
+                v_k, r_k, p_k = f(vl, vtb[:, k]), f(rl, rtb[:, k]), f(pl, pt[:, k])
+                ref_nu.scale_gradient(v_k, scale)
+                ref_nu.scale_gradient(r_k, scale)
+                ref_nu.scale_gradient(p_k, scale)
+                if k == 0:
+                    r_k = torch.zeros_like(v_k)
+                value_loss += v_k
+                reward_loss += r_k
+                policy_loss += p_k
+            loss = (value_loss * cfg.value_loss_weight + reward_loss + policy_loss) / 3
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append([loss.item(), value_loss.item(), reward_loss.item(), policy_loss.item(), opt.param_groups[0]['lr']])
+        out[f'c{ci}_losses'] = np.array(losses)
+        for k, v in net.state_dict().items():
+            out[f'c{ci}_w3_{k}'] = v.numpy().copy()
+    out['n_cases'] = np.int64(2)
+    np.savez_compressed(os.path.join(HERE, 'trainer.npz'), **out)
+    print('trainer.npz')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
+    if len(sys.argv) > 1 and sys.argv[1] == 'trainer':
+        gen_trainer()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'selfplay':
         gen_selfplay()
         sys.exit(0)
@@ -685,6 +752,7 @@ if __name__ == '__main__':
     gen_selfplay()
     gen_reanalyse()
     gen_targets()
+    gen_trainer()
     gen_misc()
     gen_hash_fixtures()
     gen_stream_fixtures()
