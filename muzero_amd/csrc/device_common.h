@@ -85,7 +85,9 @@ __device__ __forceinline__ TreeMem tree_mem(const Dev &d, int t)
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int v)
 {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);  // no valid source lane: keep own value
+    // No previous value to preserve (a lane without a valid source reads 0 and no caller uses it), so this
+    // is a single v_mov_b32_dpp, and for 32-bit operands the compiler folds it into the consuming op.
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
