@@ -133,12 +133,12 @@ __device__ __forceinline__ T gshfl(T v, int src) { return __shfl(v, src, LANES);
 template <int LANES>
 __device__ __forceinline__ double gmin(double v, int W = LANES)
 {
-    return greduce<LANES>(v, W, [](double x, double y) { return y < x ? y : x; });
+    return greduce<LANES>(v, W, [](double x, double y) { return (y < x || y != y) ? y : x; });  // np.min: NaN wins
 }
 template <int LANES>
 __device__ __forceinline__ double gmax(double v, int W = LANES)
 {
-    return greduce<LANES>(v, W, [](double x, double y) { return y > x ? y : x; });
+    return greduce<LANES>(v, W, [](double x, double y) { return (y > x || y != y) ? y : x; });  // np.max: NaN wins
 }
 template <int LANES>
 __device__ __forceinline__ float gmaxf(float v, int W = LANES)

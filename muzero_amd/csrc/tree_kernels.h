@@ -275,6 +275,7 @@ __device__ __forceinline__ int to_act_rule(const Dev &d, int t, int a, bool on, 
         double cq = qt_completed_mix<RL>(d, s, a, on, &vsum);
         int considered = gmaxi<RL>(on ? s.cv : -2147483647);
         double sc = gumbel_score<RL>(s, on, on ? d.gumbel[(long long)t * A + a] : 0.0, cq, considered);
+        sc = sc != sc ? inf : sc;   // np.argmax: the first NaN wins
         if (!on || !legal) sc = -inf;
         action = gargmax<RL>(sc, on ? a : 0x7fffffff);
         double x = s.prior + cq;

@@ -80,7 +80,7 @@ __device__ __forceinline__ double qt_parent_siblings(const Dev &d, const NodeSta
     lo = s.nval < lo ? s.nval : lo;
     hi = s.nval > hi ? s.nval : hi;
     double den = hi - lo;
-    den = den > 1e-8 ? den : 1e-8;
+    den = den < 1e-8 ? 1e-8 : den;  // np.maximum: a NaN stays a NaN
     double cq = s.cv > 0 ? q : lo;
     return (cq - lo) / den;
 }
@@ -95,7 +95,7 @@ __device__ __forceinline__ double mixed_value(const Dev &d, const NodeStats &s, 
     float es = gsum_np<LANES, float>(e, a, A);
     float p = __fdiv_rn(e, es);
     const float tiny = 1.17549435e-38f;
-    p = p > tiny ? p : tiny;
+    p = p < tiny ? tiny : p;  // np.maximum(tiny, p): a NaN (0 / 0 when every exp underflows) stays a NaN
     float pm = (on && s.cv > 0) ? p : 0.0f;
     float prob_sum = gsum_np<LANES, float>(pm, a, A);
     double pq = (on && s.cv > 0) ? (double)p * q : 0.0;
@@ -118,7 +118,7 @@ __device__ __forceinline__ double qt_completed_mix(const Dev &d, const NodeStats
     double comp = s.cv > 0 ? q : mixed;
     double lo = gmin<LANES>(on ? comp : inf), hi = gmax<LANES>(on ? comp : -inf);
     double den = hi - lo;
-    den = den > 1e-8 ? den : 1e-8;
+    den = den < 1e-8 ? 1e-8 : den;  // np.maximum: a NaN stays a NaN
     double scale = (d.c_visit + (double)vmax) * d.c_scale;
     *vsum_out = vsum;
     return scale * ((comp - lo) / den);
@@ -132,7 +132,7 @@ __device__ __forceinline__ double gumbel_score(const NodeStats &s, bool on, doub
     float lmax = gmaxf<LANES>(on ? (float)s.prior : ninf);
     float l = (float)s.prior - lmax;
     double sc = (g + (double)l) + cq;
-    sc = sc > -1e9 ? sc : -1e9;
+    sc = sc < -1e9 ? -1e9 : sc;  // np.maximum(-1e9, .) keeps a NaN
     return sc + (s.cv == considered ? 0.0 : -__builtin_huge_val());
 }
 
@@ -193,6 +193,9 @@ __device__ __forceinline__ int select_at(const Dev &d, const DescendCtx &c, cons
             score = e / es - (double)s.cv / (double)(1 + vsum);
         }
     }
+    // np.argmax treats a NaN as the maximum and returns the first one (a node whose float32 prior softmax
+    // underflows entirely scores NaN everywhere in the reference: it then takes the first legal action)
+    score = score != score ? inf : score;
     if (!on || !legal) score = -inf;
     int best = gargmax<LANES>(score, on ? a : 0x7fffffff);
     // the chosen action's child index sits in lane `best`; min over (lane == best ? ci : big) fetches it

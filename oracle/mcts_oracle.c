@@ -232,11 +232,11 @@ void orc_qtransform_by_parent_and_siblings(const orc_cfg *c, const orc_tree *t, 
     double mn = node_value, mx = node_value;
     for (int a = 0; a < A; a++) {
         double s = cv[a] > 0 ? q[a] : node_value;
-        if (s < mn) mn = s;
-        if (s > mx) mx = s;
+        if (s < mn || s != s) mn = s;   /* np.min / np.max: a NaN wins and stays */
+        if (s > mx || s != s) mx = s;
     }
     double den = mx - mn;
-    if (!(den > 1e-8)) den = 1e-8; /* np.maximum(max - min, epsilon) */
+    if (den < 1e-8) den = 1e-8; /* np.maximum(max - min, epsilon): a NaN stays a NaN */
     for (int a = 0; a < A; a++) {
         double cq = cv[a] > 0 ? q[a] : mn;
         out[a] = (cq - mn) / den;
@@ -280,12 +280,12 @@ void orc_qtransform_completed_by_mix_value(const orc_cfg *c, const orc_tree *t, 
     int32_t max_visit = cv[0];
     for (int a = 0; a < A; a++) {
         comp[a] = cv[a] > 0 ? q[a] : mixed[a];
-        if (a == 0 || comp[a] < mn) mn = comp[a];
-        if (a == 0 || comp[a] > mx) mx = comp[a];
+        if (a == 0 || comp[a] < mn || comp[a] != comp[a]) mn = comp[a];   /* np.min / np.max: a NaN wins and stays */
+        if (a == 0 || comp[a] > mx || comp[a] != comp[a]) mx = comp[a];
         if (cv[a] > max_visit) max_visit = cv[a];
     }
     double den = mx - mn;
-    if (!(den > 1e-8)) den = 1e-8;
+    if (den < 1e-8) den = 1e-8;   /* np.maximum: a NaN stays a NaN */
     double scale = (c->c_visit + (double)max_visit) * c->c_scale;
     for (int a = 0; a < A; a++) out[a] = scale * ((comp[a] - mn) / den);
 }

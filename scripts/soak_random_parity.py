@@ -1,13 +1,18 @@
-"""Soak test (not part of the suite): 400 random search configurations against the CPU checker, bit for bit."""
+"""Soak test (not part of the suite): random search configurations against the CPU checker, bit for bit.
+
+    python scripts/soak_random_parity.py [seed=777] [trials=400]
+"""
 import sys, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from helpers import make_config
 from muzero_amd import hashnet
 from muzero_amd.engine import SearchEngine
 from oracle import oracle as orc
-rng = np.random.default_rng(777)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 777
+TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+rng = np.random.default_rng(SEED)
 bad = 0
-for trial in range(400):
+for trial in range(TRIALS):
     gumbel = bool(rng.integers(2)); A = int(rng.integers(1, 65)); S = int(rng.integers(1, 120)); players = int(rng.integers(1, 3))
     gamma = float(rng.choice([1.0, 0.997, 0.9, 0.5])); H = int(rng.integers(2, 12)); B = int(rng.integers(1, 200))
     cfg = make_config(gumbel, A, S, players, gamma)
@@ -37,5 +42,5 @@ for trial in range(400):
         bad += 1
         print('MISMATCH', trial, gumbel, A, S, players, gamma, H, B, lanes, int((nv.cpu().numpy() != ref.node_visits).sum()), flush=True)
     eng.close()
-    if trial % 50 == 0: print('trial', trial, flush=True)
+    if trial % 100 == 0: print('trial', trial, flush=True)
 print('done, mismatches:', bad)

@@ -673,6 +673,37 @@ def gen_targets():
     print('targets.npz', ci, 'cases')
 
 
+def gen_nan_regime():
+    """Searches in which the reference's own scores are NaN: with logits spread over +-64 and most actions
+    illegal, the masked root priors (shifted by the maximum over ALL logits, mcts/mcts.py + utils/game_utils.py:71-78)
+    are so negative that the float32 softmax without max-subtraction (utils/utils.py:18-20) is 0 / 0."""
+    rng = np.random.default_rng(244)
+    A, S, H, B = 19, 9, 4, 48
+    cfg = make_config(True, A, S, 1, 0.5, m=2)
+    hp = hashnet.HashNetParams(A, H, 1, 0, 0)
+    net = hashnet.HashNetwork(hp)
+    legal = np.zeros((B, A))
+    for b in range(B):
+        legal[b, rng.choice(A, size=int(rng.integers(1, 4)), replace=False)] = 1
+    codes = rng.integers(0, 2**32, size=B, dtype=np.uint64).astype(np.uint32)
+    g = rng.gumbel(size=(B, A))
+    out = dict(legal=legal, codes=codes, gumbel=g, meta=np.array([A, S, H, B, 2], dtype=np.int64))
+    acts, vals, visits, probs, nan_roots = [], [], [], [], 0
+    real_gumbel = np.random.gumbel
+    try:
+        for b in range(B):
+            np.random.gumbel = lambda size=None, b=b: g[b].copy()
+            m = CapturingMCTS(cfg)
+            a, v, p = m.search(net, hashnet.observation_of(int(codes[b])), legal[b], lambda x: np.eye(A)[x], 0, 0)
+            acts.append(a); vals.append(v); probs.append(p); visits.append(np.array(m.captured.children_visits[0]))
+            nan_roots += int(np.isnan(p).any())
+    finally:
+        np.random.gumbel = real_gumbel
+    out.update(action=np.array(acts, dtype=np.int64), root_value=np.array(vals), root_visits=np.array(visits), probs=np.array(probs))
+    np.savez_compressed(os.path.join(HERE, 'nan_regime.npz'), **out)
+    print('nan_regime.npz:', nan_roots, 'of', B, 'searches return a NaN policy')
+
+
 def gen_trainer():
     """Three optimisation steps as Trainer.update_weights / update_weights_continuously perform them
     (trainer.py:43-45, 62-123; the actor itself needs ray), spelled out with the reference's own
@@ -742,6 +773,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         gen_trainer()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'nan':
+        gen_nan_regime()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'selfplay':
         gen_selfplay()
         sys.exit(0)
@@ -753,6 +787,7 @@ if __name__ == '__main__':
     gen_reanalyse()
     gen_targets()
     gen_trainer()
+    gen_nan_regime()
     gen_misc()
     gen_hash_fixtures()
     gen_stream_fixtures()

@@ -336,3 +336,31 @@ def test_random_configurations_vs_checker():
         for b in range(0, B, 9):
             assert np.array_equal(eng.export_tree(b)['children_visits'][0], ref.root_visits[b]), tag
         eng.close()
+
+
+def test_nan_regime_matches_reference():
+    """Roots whose float32 prior softmax underflows entirely (the reference's scores are all NaN there and it
+    plays the first legal action): actions, root values, root visit counts and the NaN policies equal the
+    reference's, for every group width."""
+    z = load('nan_regime.npz')
+    A, S, H, B, m = (int(x) for x in z['meta'])
+    cfg = make_config(True, A, S, 1, 0.5)
+    cfg.max_considered_actions = m
+    hp = hashnet.HashNetParams(A, H, 1, 0, 0)
+    codes, legal, g = z['codes'], z['legal'], z['gumbel']
+    for lanes in (32, 64):
+        eng = _engine(cfg, H, B, seed=0, lanes_per_tree=lanes)
+        logits = np.stack([hashnet.logits_of(int(c), hp) for c in codes])
+        prior = eng.root_prepare(logits, legal)
+        eng.reset(prior, [hashnet.value_of(int(c)) for c in codes],
+                  np.stack([hashnet.hidden_of(int(c), hp) for c in codes]), np.zeros(B, np.int32), legal, g)
+        eng.search_hash(1, 0, 0)
+        action, value, probs, _ = eng.to_act(0.0)
+        np.testing.assert_array_equal(action.cpu().numpy(), z['action'])
+        np.testing.assert_array_equal(value.cpu().numpy(), z['root_value'])
+        p = probs.cpu().numpy()
+        assert np.array_equal(np.isnan(p), np.isnan(z['probs']))
+        np.testing.assert_allclose(p[~np.isnan(p)], z['probs'][~np.isnan(z['probs'])], rtol=1e-12, atol=1e-300)
+        for b in range(B):
+            assert np.array_equal(eng.export_tree(b)['children_visits'][0], z['root_visits'][b]), (lanes, b)
+        eng.close()

@@ -138,3 +138,22 @@ def test_counter_noise_matches_host_definition():
     from muzero_amd import noise
     for seed, tree, call, a in [(0, 0, 0, 0), (7, 3, 11, 8), (2**40 + 5, 16383, 4000, 17)]:
         assert orc.lib().orc_noise_u(seed, tree, call, a) == noise.noise_u(seed, tree, call, a)
+
+
+def test_nan_regime_matches_reference():
+    """Roots whose float32 prior softmax underflows entirely: the reference's scores are NaN and NumPy's NaN
+    rules decide (maximum / min / max keep a NaN, argmax returns the first one)."""
+    import os
+    from muzero_amd import hashnet
+    from helpers import make_config
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'nan_regime.npz'))
+    A, S, H, B, m = (int(x) for x in z['meta'])
+    cfg = make_config(True, A, S, 1, 0.5)
+    cfg.max_considered_actions = m
+    hp = hashnet.HashNetParams(A, H, 1, 0, 0)
+    ref = orc.search_batch_hash(cfg, hp, H, z['codes'], z['legal'], np.zeros(B, np.int32), gumbel=z['gumbel'], seed=0,
+                                n_threads=2)
+    assert np.isnan(z['probs']).any(axis=1).sum() >= 5          # the fixture does contain the regime
+    np.testing.assert_array_equal(ref.action, z['action'])
+    np.testing.assert_array_equal(ref.root_value, z['root_value'])
+    np.testing.assert_array_equal(ref.root_visits, z['root_visits'])
