@@ -392,7 +392,7 @@ __device__ __forceinline__ double root_prior(float lg, bool on, bool lgl, double
         float keep = (float)(1.0 - frac);
         double noised = (double)(keep * p) + frac * (on ? dirichlet_a : 0.0);
         const double tiny = 2.2250738585072014e-308;
-        double l = log(noised > tiny ? noised : tiny);
+        double l = log(noised < tiny ? tiny : noised);  // np.maximum keeps a NaN (softmax of logits beyond the float32 exp range)
         double mx = gmax<LANES>(on ? l : -__builtin_huge_val());
         if (!shift_and_mask) return l;
         return lgl ? l - mx : -1.7976931348623157e308;

@@ -543,7 +543,7 @@ void orc_puct_root_prior(int A, const float *logits, const double *dirichlet, do
         const double tiny = 2.2250738585072014e-308;
         if (!(noised > tiny)) noised = (noised != noised) ? noised : tiny;
         out[a] = log(noised);
-        if (a == 0 || out[a] > mx) mx = out[a];
+        if (a == 0 || out[a] > mx || out[a] != out[a]) mx = out[a];   /* np.max: a NaN wins and stays */
     }
     for (int a = 0; a < A; a++) out[a] = legal[a] != 0 ? out[a] - mx : -1.7976931348623157e308;
 }
