@@ -29,7 +29,7 @@ for trial in range(TRIALS):
         return np.round(x / q) * q if q else x
     logits = draw((B, S, A), float(rng.choice([0.5, 3.0, 20.0]))).astype(np.float32)
     value = draw((B, S), 1.0); reward = draw((B, S), 1.0) * float(rng.integers(2))
-    root_logits = draw((B, A), 2.0).astype(np.float32); root_value = draw((B,), 1.0)
+    root_logits = draw((B, A), float(rng.choice([2.0, 60.0]))).astype(np.float32); root_value = draw((B,), 1.0)
     legal = np.ones((B, A))
     if A > 2 and rng.integers(2):
         for b in range(B):
@@ -56,6 +56,15 @@ for trial in range(TRIALS):
         eng.expand_backup(logits[:, s], value[:, s], reward[:, s], None)
     prior_h = prior.cpu().numpy()
     ok = True
+    for b in range(B):   # root preparation itself (float64 log may differ from libm in the last bit; NaN where the reference has NaN)
+        want = orc.gumbel_root_prior(root_logits[b], legal[b]) if gumbel else orc.puct_root_prior(root_logits[b], di[b], 0.25, legal[b])
+        fin = np.isfinite(want) & (legal[b] != 0)
+        tol = 0 if gumbel else 4e-16 * max(1.0, float(np.abs(want[fin]).max()) if fin.any() else 1.0)
+        if not (np.array_equal(np.isnan(want), np.isnan(prior_h[b])) and np.allclose(prior_h[b][fin], want[fin], rtol=0, atol=tol)
+                and np.array_equal(prior_h[b][legal[b] == 0], want[legal[b] == 0])):
+            ok = False
+            print('ROOT PRIOR MISMATCH trial', trial, 'tree', b, flush=True)
+            break
     for b in range(B):
         o = orc.Oracle(cfg, 0)
         o.init(prior_h[b], root_value[b], None, to_play[b], legal[b], None if g is None else g[b])
