@@ -56,6 +56,9 @@ for trial in range(TRIALS):
         eng.expand_backup(logits[:, s], value[:, s], reward[:, s], None)
     prior_h = prior.cpu().numpy()
     ok = True
+    T = float(rng.choice([0.0, 0.5, 1.0]))
+    uu = rng.random(B)
+    act_e, val_e, probs_e, q_e = (x.cpu().numpy() for x in eng.to_act(T, uu))
     for b in range(B):   # root preparation itself (float64 log may differ from libm in the last bit; NaN where the reference has NaN)
         want = orc.gumbel_root_prior(root_logits[b], legal[b]) if gumbel else orc.puct_root_prior(root_logits[b], di[b], 0.25, legal[b])
         fin = np.isfinite(want) & (legal[b] != 0)
@@ -74,6 +77,10 @@ for trial in range(TRIALS):
         same = np.array_equal(r.parent, seq[b, :, 0]) and np.array_equal(r.action, seq[b, :, 1])
         for f in FIELDS:
             same = same and np.array_equal(np.asarray(t[f]).reshape(o.arrays[f].shape), o.arrays[f], equal_nan=True)
+        a_o, p_o, q_o = o.to_act(T, uu[b])
+        same = same and int(act_e[b]) == a_o and float(val_e[b]) == float(o.arrays['node_values'][0])
+        same = same and np.allclose(probs_e[b], p_o, rtol=1e-12, atol=1e-300, equal_nan=True)
+        same = same and np.allclose(q_e[b], q_o, rtol=1e-12, atol=1e-300, equal_nan=True)
         if not same:
             ok = False
             first = int(np.nonzero((r.parent != seq[b, :, 0]) | (r.action != seq[b, :, 1]))[0][0]) if not (np.array_equal(r.parent, seq[b, :, 0]) and np.array_equal(r.action, seq[b, :, 1])) else -1
