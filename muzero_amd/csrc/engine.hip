@@ -387,9 +387,14 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         if (c->lanes == 64)
             while (gpb > 1 && (c->B + gpb - 1) / gpb < 256) gpb >>= 1;
         if (const char *e = getenv("MZ_GROUPS_PER_BLOCK")) { int v = atoi(e); if (v >= 1 && v <= MZ_BLOCK / c->lanes) gpb = v; }
+        // The kernel's static tables (backup staging, PUCT c(n) and sqrt tables) share the 160 KB with the
+        // weights and the per-group activations: narrow groups give up groups per block until all fit.
+        const size_t lds_static = (size_t)MZ_BLOCK * 8 + (c->cfg.gumbel ? 32 : (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8);
+        auto lds_for = [&](int g) { return ((size_t)c->net.n_data + c->net.n_meta + (size_t)g * c->net_scratch) * 4; };
+        while (gpb * c->lanes > 64 && lds_for(gpb) + lds_static > 160 * 1024) gpb >>= 1;
         const unsigned n_blocks = (unsigned)((c->B + gpb - 1) / gpb), n_threads = (unsigned)(gpb * c->lanes);
-        size_t lds = ((size_t)c->net.n_data + c->net.n_meta + (size_t)gpb * c->net_scratch) * 4;
-        if (lds > 160 * 1024)
+        const size_t lds = lds_for(gpb);
+        if (lds + lds_static > 160 * 1024)
             return fail(MZ_ERR_ARG, "mz_search_run: network does not fit in LDS for the fused search; use the step API");
         // Small batches are latency-bound: whole-wave groups keep their trees in LDS when one block per CU
         // covers the batch and everything fits beside the kernel's static tables.
@@ -397,7 +402,6 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         const int tree_lds = ((L.N * L.rec + 15) & ~15) + ((L.N * L.H * 4 + 15) & ~15) + ((L.S * 4 + 15) & ~15) +
                              ((L.N * 4 + 15) & ~15);
         const size_t lds_tree = ((lds + 15) & ~(size_t)15) + (size_t)gpb * tree_lds;
-        const size_t lds_static = (size_t)MZ_BLOCK * 8 + (c->cfg.gumbel ? 32 : (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8);
         bool tree_in_lds = c->lanes == 64 && n_blocks <= 256 && lds_tree + lds_static <= 160 * 1024;
         if (const char *e = getenv("MZ_TREE_LDS")) tree_in_lds = tree_in_lds && atoi(e) != 0;
         hipError_t attr_err = hipSuccess;

@@ -220,3 +220,46 @@ def test_mfma_leaf_evaluation_matches_torch_network(name, B, monkeypatch):
         np.testing.assert_array_equal(results[0][1], results[k][1])
     assert (results[0][0] == results[4][0]).mean() >= 0.97
     assert (np.abs(results[0][1] - results[4][1]) < 1e-5).mean() >= 0.97
+
+
+@pytest.mark.parametrize('lanes', [16, 64])
+def test_networks_near_the_lds_limit_fit_or_fail_cleanly(lanes):
+    """Weights, per-group activations and the kernel's own static tables share one CU's 160 KB of LDS.
+    Networks sized around that limit must either run (agreeing with the checker) or be rejected with an
+    error by the host - never reach the launch with more LDS than the hardware has."""
+    from types import SimpleNamespace
+    from muzero_amd.engine import SearchEngine
+    from oracle import oracle as orc
+    B, A, S = 64, 2, 12
+    ran = rejected = 0
+    for width in (64, 72, 80, 88, 96, 104):
+        ncfg = SimpleNamespace(network='mlp', observation_dim=[1, 1, 4], n_actions=A, n_stacked_observations=1,
+                               encoding_size=64, fc_reward_layers=[width], fc_policy_layers=[width],
+                               fc_value_layers=[width], fc_representation_layers=[], fc_hidden_state_layers=[width],
+                               support_limit=10)
+        net = MuZeroNetwork(ncfg, seed=width)
+        packed = pack_network(net)
+        rng = np.random.default_rng(width)
+        cfg = make_config(False, A, S, 1, 0.997)
+        obs, logits, hidden, value = _roots(net, B, (1, 1, 4), rng)
+        legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+        di = rng.dirichlet([0.25] * A, size=B)
+        eng = SearchEngine(cfg, packed.H, B, seed=3, lanes_per_tree=lanes)
+        try:
+            eng.set_network(packed)
+            prior = eng.root_prepare(logits, legal, di, 0.25)
+            eng.reset(prior, value, hidden, tp, legal)
+            eng.search_net()
+        except ValueError:
+            rejected += 1
+            eng.close()
+            continue
+        ran += 1
+        ref = orc.search_batch_net(cfg, packed, logits, hidden, value, legal, tp, dirichlet=di, frac=0.25, seed=3,
+                                   tree_id0=0, n_threads=8)
+        nv, _ = eng.stats()
+        assert (nv.cpu().numpy() == ref.node_visits).mean() >= 0.95
+        _, rv, _, _ = eng.to_act(0.0)
+        assert (np.abs(rv.cpu().numpy() - ref.root_value) < 1e-5).mean() >= 0.95
+        eng.close()
+    assert ran >= 1 and rejected >= 1, (ran, rejected)
