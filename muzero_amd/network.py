@@ -200,6 +200,8 @@ class MuZeroDenseNetwork:
         self.hidden_shape = (C, h, w)
         self.norm_groups = C
         self.action_size = h * w           # board plane, games/tictactoe.py:66-69
+        if self.A > self.action_size:
+            raise ValueError(f'{self.A} actions do not fit a {h}x{w} action plane (one cell per action)')
         blocks = int(c.blocks)
         rep, dyn, pred = DenseProgram(), DenseProgram(), DenseProgram()
         # representation: ConvBlock + residual tower

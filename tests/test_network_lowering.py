@@ -114,3 +114,13 @@ def test_packed_program_checker_matches_reference_outputs(name):
     np.testing.assert_allclose(nh, z['rec_hidden'].reshape(nh.shape), atol=HTOL, rtol=0)
     np.testing.assert_allclose(val, z['rec_value'], atol=TOL, rtol=0)
     np.testing.assert_allclose(rew, z['rec_reward'], atol=TOL, rtol=0)
+
+
+def test_action_plane_smaller_than_action_count_is_rejected():
+    """The ResNet dynamics input encodes an action as one cell of a board-sized plane
+    (games/tictactoe.py:66-69): more actions than cells cannot be encoded."""
+    from muzero_amd.network import MuZeroNetwork
+    cfg = net_config('resnet_tictactoe')
+    cfg.observation_dim = [3, 2, 2]
+    with pytest.raises(ValueError):
+        MuZeroNetwork(cfg, seed=0)
