@@ -160,7 +160,10 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, float *act, 
 // Epilogue of one tree by its group of LANES lanes: next hidden state (per-group min-max scaling,
 // utils/network_utils.py:132-158) into `hidden_dst`, value and reward (support_to_scalar,
 // utils/network_utils.py:75-96).  The policy logits stay in the tree's row at io[4].
-template <int LANES = 16>
+// SUP = lanes that reduce the supports: the float32 sums depend on it, so every path that must agree bit for
+// bit with the 16-lane groups of the tile-resident kernels uses 16 (each 16-lane row of a wider group then
+// computes the same thing).
+template <int LANES = 16, int SUP = LANES>
 __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *row, int a, float *hidden_dst,
                                                double *value, double *reward)
 {
@@ -177,7 +180,7 @@ __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *r
     } else {
         minmax_to<LANES>(row + net.io[2], H, ngroups, a, hidden_dst, nullptr);
     }
-    support_to_scalar2<LANES>(row + net.io[5], row + net.io[3], sup, a, value, reward);
+    support_to_scalar2<SUP>(row + net.io[5], row + net.io[3], sup, a % SUP, value, reward);
 }
 
 // recurrent_inference (network.py:105-126) for every tree's pending selection, then nothing else:
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level(Dev d, MfmaNet 
 
 // Epilogue of the per-level path: one group of LANES (16 or 64) lanes per tree reads its row of `acts`.
 // The reductions are order-insensitive except for the float32 sums of the supports, whose order depends
-// on LANES: 16 gives the tile-resident kernels' results bit for bit, 64 is faster for long supports.
+// on the lanes that share them: supports of up to 64 bins are always reduced by 16 lanes (the tile-resident
+// kernels' results bit for bit); longer ones by the whole wave when LANES is 64 (faster, last-bit differences).
 template <int LANES>
 __global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int leaf, const float *acts, float *out_logits,
                                                        double *out_value, double *out_reward)
@@ -269,7 +273,9 @@ __global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int le
     const int H = net.io[6], A = net.io[7];
     const float *row = acts + (long long)t * net.stride;
     double value, reward;
-    tile_epilogue<LANES>(net, row, a, d.hidden + ((long long)t * d.L.N + leaf) * H, &value, &reward);
+    float *hidden_dst = d.hidden + ((long long)t * d.L.N + leaf) * H;
+    if (LANES == 64 && net.io[9] <= 64) tile_epilogue<LANES, 16>(net, row, a, hidden_dst, &value, &reward);
+    else tile_epilogue<LANES, LANES>(net, row, a, hidden_dst, &value, &reward);
     for (int j = a; j < A; j += LANES) out_logits[(long long)t * A + j] = row[net.io[4] + j];
     if (a == 0) { out_value[t] = value; out_reward[t] = reward; }
 }

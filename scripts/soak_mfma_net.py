@@ -2,7 +2,10 @@
 networks and batch sizes.  (1) One network step against the same network run by torch (1e-5; hidden
 1e-4); (2) the stepped, backup+selection-fused, whole-search and layer-by-layer launch modes must give the
 same trees bit for bit (long supports on the layer-by-layer path excepted: another float32 sum order);
-(3) whole searches agree with torch-evaluated leaves on (nearly) every tree.
+(3) whole searches agree with torch-evaluated leaves on (nearly) every tree.  Boards start at 3x3: on
+2x2 boards the reference's per-plane min-max scaling (4 cells per plane) amplifies a one-ulp difference in a
+hidden state by 3-10x per recurrent step, so two float32 evaluators drift apart by more than 1e-5 along deep
+paths whatever their quality.
 
     python scripts/soak_mfma_net.py [seed=1] [trials=40]
 """
@@ -28,7 +31,7 @@ for trial in range(TRIALS):
     gamma = float(rng.choice([1.0, 0.997])); B = int(rng.integers(1, 400))
     L = int(rng.choice([1, 5, 10, 30, 100]))
     if rng.integers(3) == 0:
-        side = int(rng.integers(2, 5)); A = int(rng.integers(2, min(12, side * side + 1))); ch = int(rng.choice([8, 16, 24]))
+        side = int(rng.integers(3, 5)); A = int(rng.integers(2, min(12, side * side + 1))); ch = int(rng.choice([8, 16, 24]))
         red = int(rng.choice([2, 4, 8])); fc = int(rng.choice([8, 16, 32]))
         ncfg = SimpleNamespace(network='resnet', observation_dim=[3, side, side], n_actions=A, n_stacked_observations=1,
                                blocks=int(rng.integers(1, 3)), channels=ch, reduced_channels_reward=red,
@@ -111,7 +114,7 @@ for trial in range(TRIALS):
         continue
     for k in ('mfma_fused', 'mfma_search', 'mfma_level'):
         if k not in results or results[k] is base: continue
-        if k == 'mfma_level' and 2 * L + 1 > 32:
+        if k == 'mfma_level' and 2 * L + 1 > 64:
             same = (base[0] == results[k][0]).mean() >= 0.97 and (np.abs(base[1] - results[k][1]) < 1e-5).mean() >= 0.97
         else:
             same = all(np.array_equal(base[i], results[k][i]) for i in range(3))
