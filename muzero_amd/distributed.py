@@ -81,3 +81,25 @@ def gather_root_stats(action: torch.Tensor, root_value: torch.Tensor, probs: tor
         return None
     full = torch.cat(out, dim=0).to(probs.device)
     return full[:, 0].to(torch.int32), full[:, 1].contiguous(), full[:, 2:].contiguous()
+
+
+def broadcast_weights(state_dict: dict, src: int = 0, device=None) -> dict:
+    """The learner's weights to every search rank, as ONE broadcast of a flat float32 buffer (replaces the
+    reference's per-actor `shared_storage.get_info('model_state_dict')` pull, self_play.py:37 /
+    reanalyse.py:38-42).  Every rank passes a state dict of the same architecture (its current weights);
+    the tensors are overwritten in place with `src`'s values and the dict is returned.  Non-float entries
+    (BatchNorm's step counters) travel as float32 and are cast back."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return state_dict
+    keys = sorted(state_dict)
+    dev = device if device is not None else reduce_device(next(iter(state_dict.values())).device)
+    flat = torch.cat([state_dict[k].detach().reshape(-1).to(torch.float32) for k in keys]).to(dev)
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for k in keys:
+            t = state_dict[k]
+            n = t.numel()
+            t.copy_(flat[off:off + n].reshape(t.shape).to(device=t.device, dtype=t.dtype))
+            off += n
+    return state_dict

@@ -35,6 +35,12 @@ def _worker(rank, world, port, out_dir):
     slow = mzdist.max_over_ranks(1.0 + rank)
     total = mzdist.sum_over_ranks(float(b))
     assert slow == float(world) and total == float(B_total)
+    # weight refresh: every rank ends up with rank 0's tensors, dtypes kept
+    sd = {'w': torch.full((3, 2), float(rank + 1)), 'b': torch.arange(4, dtype=torch.float32) * (rank + 1),
+          'steps': torch.tensor(7 * (rank + 1), dtype=torch.int64)}
+    out = mzdist.broadcast_weights(sd, src=0)
+    assert out is sd and sd['steps'].dtype == torch.int64 and int(sd['steps']) == 7
+    assert torch.equal(sd['w'], torch.full((3, 2), 1.0)) and torch.equal(sd['b'], torch.arange(4, dtype=torch.float32))
     if rank == 0:
         a, v, p = res
         assert torch.equal(a, g_action) and torch.equal(v, g_value) and torch.equal(p, g_probs)
