@@ -15,6 +15,7 @@
 #include "dense_net.h"
 #include "net_mfma.h"      // matrix-core leaf evaluation; uses the epilogue helpers of dense_net.h
 #include "search_net.h"
+#include "search_reg.h"
 #include "env_step.h"
 #include "targets.h"
 
@@ -44,6 +45,7 @@ struct mz_ctx {
     int32_t *node_act;  // device scratch
     NetDev net;         // uploaded dense-program network (mz_set_network)
     int net_scratch;    // activation floats per tree
+    bool net_small;     // the program fits the register-cached evaluator and the whole-wave epilogue
     void *net_meta_d, *net_data_d;
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
@@ -124,7 +126,7 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     c->cfg.c_table_h = nullptr;
     c->lanes = lanes;
     c->n_expanded = 0; c->selected = 0; c->B = 0;
-    memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_meta_d = c->net_data_d = nullptr;
+    memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_small = false; c->net_meta_d = c->net_data_d = nullptr;
     memset(&c->root, 0, sizeof c->root); memset(c->root_bufs, 0, sizeof c->root_bufs);
     memset(&c->mnet, 0, sizeof c->mnet); memset(c->mnet_bufs, 0, sizeof c->mnet_bufs);
     Dev &d = c->d;
@@ -405,6 +407,21 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         bool tree_in_lds = c->lanes == 64 && n_blocks <= 256 && lds_tree + lds_static <= 160 * 1024;
         if (const char *e = getenv("MZ_TREE_LDS")) tree_in_lds = tree_in_lds && atoi(e) != 0;
         hipError_t attr_err = hipSuccess;
+        // 2-action PUCT trees of at most 64 nodes served by whole waves: the tree lives in registers
+        const int hid_bytes = (L.N * L.H * 4 + 15) & ~15;
+        const size_t lds_reg = ((lds + 15) & ~(size_t)15) + (size_t)gpb * hid_bytes;
+        bool tree_in_regs = c->lanes == 64 && !c->cfg.gumbel && L.A == 2 && L.N <= 64 && c->net_small && !L.prior_f32 &&
+                            lds_reg + (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8 <= 160 * 1024;
+        if (const char *e = getenv("MZ_TREE_REG")) tree_in_regs = tree_in_regs && atoi(e) != 0;
+        if (tree_in_regs) {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_reg),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
+            hipLaunchKernelGGL(k_search_reg, dim3(n_blocks), dim3(n_threads), lds_reg, (hipStream_t)stream, c->d, c->net,
+                               c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch, hid_bytes);
+            c->n_expanded += n_sims;
+            return launch_status("mz_search_run");
+        }
         dispatch_shape(c->lanes, c->rl, c->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) {
             constexpr int LN = decltype(L_)::value, RN = decltype(R_)::value;
             constexpr bool GM = decltype(G_)::value;
@@ -690,6 +707,11 @@ extern "C" int mz_set_network(mz_ctx *c, const int32_t *meta_h, int32_t n_meta, 
     c->net.n_meta = n_meta; c->net.n_data = n_data;
     memcpy(c->net.io, io_h, sizeof c->net.io);
     c->net_scratch = meta_h[1];
+    // at most 2 levels of at most 64 rows over at most 16 inputs, one normalisation group of at most 16
+    // hidden values, supports of at most 32 bins: what dense_run_cached and epilogue_wave_small serve
+    c->net_small = meta_h[0] <= 2 && io_h[10] == 1 && io_h[6] <= 16 && io_h[9] <= 32;
+    for (int l = 0; l < meta_h[0]; l++)
+        if (lv[4 * l] > 64 || lv[4 * l + 1] > 16) c->net_small = false;
     return MZ_OK;
 }
 

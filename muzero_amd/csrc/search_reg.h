@@ -1,0 +1,223 @@
+// Whole PUCT search of a 2-action tree of at most 64 nodes by ONE wavefront with the tree in registers:
+// lane j owns node j (header fields and both actions' statistics, ~25 registers), so
+//  * selection (mcts/action_selection.py:25-49 with mcts/qtransforms.py:7-22) is evaluated at every node at
+//    once without a single memory access or cross-lane step - both actions of a node sit in the same lane -
+//    and the descent (mcts/mcts.py:98-114) is read off with one lane read per level;
+//  * the backup (mcts/mcts.py:143-164) updates every node of the path in its own lane; only the discounted
+//    return, a serial recurrence over the path's rewards, walks the levels (lane reads), and the child's
+//    new mean reaches its parent's lane with one cross-lane read;
+//  * expansion (mcts/mcts.py:116-141) is a predicated register write in the leaf's and the parent's lanes.
+// Small batches are bound by the latency of one wave's dependent instructions and LDS round trips, not by
+// bandwidth; this form removes nearly all LDS traffic of the tree.  Hidden states stay in LDS, the
+// network is evaluated exactly as in k_search_net (register-cached weights, wave epilogue).  Every
+// expression is the one the lane-group kernels evaluate (tree_ops.h), so trees are identical bit for bit.
+#pragma once
+#include "search_net.h"
+
+namespace mz {
+
+__device__ __forceinline__ double lane_read(double v, int lane)  // lane: wave-uniform
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// One tree per wave; the block may hold several waves.  Dynamic LDS: weights | program | per-wave
+// activation scratch | per-wave hidden states [N][H] (`hid_bytes` each, 16-byte aligned).
+// Requires (checked by the host): PUCT, A == 2, N <= 64, a program dense_run_cached serves, one
+// normalisation group of at most 16 hidden values and supports of at most 32 bins.
+__global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int first_leaf, int n_sims,
+                                                          const double *noise, int noise_max_calls,
+                                                          int scratch_floats, int hid_bytes)
+{
+    extern __shared__ __align__(16) float lds[];
+    float *w = lds;
+    int32_t *meta = reinterpret_cast<int32_t *>(lds + net.n_data);
+    float *scratch0 = lds + net.n_data + net.n_meta;
+    const int n_threads = blockDim.x, waves_per_block = n_threads / 64;
+    const int wv = threadIdx.x / 64, lane = threadIdx.x % 64;
+    for (int i = threadIdx.x; i < net.n_data; i += n_threads) w[i] = net.data[i];
+    for (int i = threadIdx.x; i < net.n_meta; i += n_threads) meta[i] = net.meta[i];
+    float *sc = scratch0 + (size_t)wv * scratch_floats;
+    for (int i = lane; i < scratch_floats; i += 64) sc[i] = 0.0f;
+    __shared__ __align__(16) double s_ct[MZ_CT_LDS];
+    const double *ct = stage_c_table<false>(d, s_ct);
+    __shared__ __align__(16) double s_sq[MZ_SQ_LDS];
+    const double *sqt = stage_sqrt_table<false>(d, s_sq);
+    __syncthreads();
+    const int t = (int)blockIdx.x * waves_per_block + wv;
+    if (t >= d.B) return;
+    const int H = d.L.H, S = d.L.S;
+    size_t base = ((size_t)(net.n_data + net.n_meta) + (size_t)waves_per_block * scratch_floats) * 4;
+    base = (base + 15) & ~(size_t)15;
+    float *hid = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + base + (size_t)wv * hid_bytes);
+    float *const hid_global = d.hidden + (long long)t * d.L.N * H;
+    const TreeMem mg = tree_mem(d, t);
+    for (int i = lane; i < first_leaf * H; i += 64) hid[i] = hid_global[i];
+
+    // ---- this lane's node
+    int nv = 0, par = -1, afp = -1, tp = 0, dep = 0;
+    double nval = 0.0, raw = 0.0;
+    int cv0 = 0, cv1 = 0, ci0 = -1, ci1 = -1;
+    double pr0 = 0.0, pr1 = 0.0, r0 = 0.0, r1 = 0.0, v0 = 0.0, v1 = 0.0;
+    if (lane < first_leaf) {
+        const RowView rv = view(d, mg, lane);
+        const NodeHdr h = *rv.hdr;
+        nv = h.visits; par = h.parent; afp = h.afp; tp = h.to_play; nval = h.value; raw = h.raw;
+        cv0 = rv.cvis.get(0); cv1 = rv.cvis.get(1); ci0 = rv.cidx.get(0); ci1 = rv.cidx.get(1);
+        const double *pp = reinterpret_cast<const double *>(rv.prior);
+        pr0 = pp[0]; pr1 = pp[1]; r0 = rv.crew[0]; r1 = rv.crew[1]; v0 = rv.cval[0]; v1 = rv.cval[1];
+    }
+    for (int n = 1; n < first_leaf; n++) {  // parents precede their children: one forward sweep gives every depth
+        const int p = __builtin_amdgcn_readlane(par, n);
+        const int dp = __builtin_amdgcn_readlane(dep, p) + 1;
+        dep = lane == n ? dp : dep;
+    }
+
+    const double inf = __builtin_huge_val();
+    const unsigned long long key = noise_key(d.seed, d.tree_id0 + (unsigned long long)t);
+    const unsigned long long legal = d.legal[t];
+    const bool legal0 = lane != 0 || (legal & 1ull), legal1 = lane != 0 || ((legal >> 1) & 1ull);
+    const double *nz = noise ? noise + (long long)t * noise_max_calls * 2 : nullptr;
+    uint32_t calls = d.noise_calls[t];
+    long long visited = 0;
+    const int asz = net.io[8], sup = net.io[9];
+    DenseRegs<2, 4> regs;
+    dense_cache_load<64, 2, 4>(meta, w, lane, regs);
+    lds_fence();
+#ifdef MZ_STAMPS
+    long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_in = 0, st_mm = 0, st_t;
+    st_t = clock64();
+#endif
+    for (int s = 0; s < n_sims; s++) {
+        const int leaf = first_leaf + s;
+        // ---- selection at every node (this lane: its node, both actions)
+        const uint32_t call = calls + (uint32_t)dep;
+        double u0 = 0.0, u1 = 0.0;
+        if (d.noise_mode == 0) {
+            u0 = noise_from_key(key, call, 0u);
+            u1 = noise_from_key(key, call, 1u);
+        } else if (d.noise_mode == 1 && (int)call < noise_max_calls) {
+            u0 = nz[(long long)call * 2];
+            u1 = nz[(long long)call * 2 + 1];
+        }
+        const double q0 = r0 + d.discount * v0, q1 = r1 + d.discount * v1;
+        const double s0 = cv0 > 0 ? q0 : nval, s1 = cv1 > 0 ? q1 : nval;
+        // min / max over the two actions as each action's lane of a 2-lane group computes them (np.min /
+        // np.max: a NaN wins)
+        double lo0 = (s1 < s0 || s1 != s1) ? s1 : s0, lo1 = (s0 < s1 || s0 != s0) ? s0 : s1;
+        double hi0 = (s1 > s0 || s1 != s1) ? s1 : s0, hi1 = (s0 > s1 || s0 != s0) ? s0 : s1;
+        lo0 = nval < lo0 ? nval : lo0; lo1 = nval < lo1 ? nval : lo1;
+        hi0 = nval > hi0 ? nval : hi0; hi1 = nval > hi1 ? nval : hi1;
+        double den0 = hi0 - lo0, den1 = hi1 - lo1;
+        den0 = den0 < 1e-8 ? 1e-8 : den0; den1 = den1 < 1e-8 ? 1e-8 : den1;
+        const double cq0 = cv0 > 0 ? q0 : lo0, cq1 = cv1 > 0 ? q1 : lo1;
+        const double nq0 = (cq0 - lo0) / den0, nq1 = (cq1 - lo1) / den1;
+        const double cc = ct ? ct[nv] : d.c_table[nv];
+        const double sq0 = sqt ? sqt[nv * (S + 1) + cv0] : sqrt((double)nv / (double)(1 + cv0));
+        const double sq1 = sqt ? sqt[nv * (S + 1) + cv1] : sqrt((double)nv / (double)(1 + cv1));
+        const double uu0 = cc * pr0 + sq0, uu1 = cc * pr1 + sq1;
+        double sc0 = (uu0 + nq0) + 1e-7 * u0, sc1 = (uu1 + nq1) + 1e-7 * u1;
+        sc0 = sc0 != sc0 ? inf : sc0; sc1 = sc1 != sc1 ? inf : sc1;  // np.argmax: a NaN is the maximum
+        if (!legal0) sc0 = -inf;
+        if (!legal1) sc1 = -inf;
+        const int best = sc1 > sc0 ? 1 : 0;  // first maximum
+        const int chosen_child = best ? ci1 : ci0;
+        const int pack = ((chosen_child + 1) << 8) | best;
+        // ---- descent: follow the decisions from the root
+        int node = 0, depth = 0, ntp = 0, action = 0, pathreg = 0;
+        unsigned long long onpath = 0ull;
+        while (true) {
+            const int pk = __builtin_amdgcn_readlane(pack, node);
+            action = pk & 0xff;
+            const int child = (pk >> 8) - 1;
+            onpath |= 1ull << node;
+            pathreg = lane == depth ? node : pathreg;  // lane i: the path's node at depth i
+            ntp = d.players == 1 ? ntp : 1 - ntp;
+            depth++;
+            if (child < 0 || child >= leaf || depth > S) break;
+            node = child;
+        }
+        const int parent = node;
+        calls += (uint32_t)depth;
+        visited += depth + 1;
+#ifdef MZ_STAMPS
+        MZ_STAMP(st_sel)
+#endif
+        // ---- leaf evaluation: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
+        const float *ph = hid + parent * H;
+        for (int i = lane; i < H; i += 64) sc[net.io[0] + i] = ph[i];
+        for (int i = lane; i < asz; i += 64) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
+        lds_fence();
+#ifdef MZ_STAMPS
+        MZ_STAMP(st_in)
+#endif
+        dense_run_cached<2, 4>(regs, sc);
+#ifdef MZ_STAMPS
+        MZ_STAMP(st_net)
+#endif
+        double value, reward;
+        epilogue_wave_small(sc + net.io[2], H, sc + net.io[5], sc + net.io[3], sup, lane, hid + leaf * H, &value, &reward);
+        const float lg0 = sc[net.io[4]], lg1 = sc[net.io[4] + 1];
+#ifdef MZ_STAMPS
+        MZ_STAMP(st_mm)
+#endif
+        // ---- backup.  Level i above the leaf is the path's node at depth (depth - 1 - i); its return is
+        // L_i with L_0 = value, L_{i+1} = reward_i + gamma L_i (reward_0 = the new edge's reward).
+        double L = value, myL = 0.0;
+        const double rsel = best ? r1 : r0;  // reward of the edge this node's decision follows
+        for (int i = 0; i < depth; i++) {
+            const int nd = __builtin_amdgcn_readlane(pathreg, depth - 1 - i);
+            myL = lane == nd ? L : myL;
+            const double ri = i == 0 ? reward : lane_read(rsel, nd);
+            L = ri + d.discount * L;
+        }
+        const bool onp = (onpath >> lane) & 1ull;
+        const double newV = (nval * (double)nv + (tp == ntp ? myL : -myL)) / (double)(nv + 1);
+        const double below = __shfl(newV, chosen_child & 63, 64);  // the path child's new mean (its lane = its index)
+        const double child_new = lane == parent ? value : below;
+        if (onp) {
+            nv += 1;
+            nval = newV;
+            if (best) { v1 = child_new; cv1 += 1; } else { v0 = child_new; cv0 += 1; }
+        }
+        // ---- expansion
+        if (lane == parent) {
+            if (action) { ci1 = leaf; r1 = reward; } else { ci0 = leaf; r0 = reward; }
+        }
+        if (lane == leaf) {
+            nv = 1; par = parent; afp = action; tp = ntp; nval = value; raw = value; dep = depth;
+            cv0 = 0; cv1 = 0; ci0 = -1; ci1 = -1;
+            pr0 = (double)lg0; pr1 = (double)lg1; r0 = 0.0; r1 = 0.0; v0 = 0.0; v1 = 0.0;
+        }
+        lds_fence();
+#ifdef MZ_STAMPS
+        MZ_STAMP(st_bk)
+#endif
+    }
+    if (lane == 0) {
+        d.noise_calls[t] = calls;
+        d.visit_total[t] += visited;
+    }
+    // ---- write the tree back
+    const int live = first_leaf + n_sims;
+    if (lane < live) {
+        const RowView rv = view(d, mg, lane);
+        NodeHdr h;
+        h.visits = nv; h.parent = par; h.afp = afp; h.to_play = tp; h.value = nval; h.raw = raw;
+        *rv.hdr = h;
+        rv.cvis.set(0, cv0); rv.cvis.set(1, cv1); rv.cidx.set(0, ci0); rv.cidx.set(1, ci1);
+        double *pp = reinterpret_cast<double *>(rv.prior);
+        pp[0] = pr0; pp[1] = pr1; rv.crew[0] = r0; rv.crew[1] = r1; rv.cval[0] = v0; rv.cval[1] = v1;
+    }
+    for (int i = lane; i < live * H; i += 64) hid_global[i] = hid[i];
+#ifdef MZ_STAMPS
+    if (lane == 0) {
+        long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
+        o[0] = st_sel; o[1] = st_net; o[2] = st_epi; o[3] = st_bk; o[4] = st_in; o[5] = st_mm;
+    }
+#endif
+}
+
+}  // namespace mz

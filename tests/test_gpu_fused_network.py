@@ -89,24 +89,28 @@ def test_fused_equals_step_mode_with_torch_network():
 
 @pytest.mark.parametrize('gumbel', [False, True])
 def test_lds_resident_tree_is_bit_identical(gumbel, monkeypatch):
-    """Small batches keep their trees in LDS and score every node of a 2-action tree at once; the
-    arithmetic is the same as the global-memory, level-by-level kernel, so whole trees must be equal
-    bit for bit - also when the fused search takes over after a few stepped simulations."""
+    """Small batches keep their trees in LDS and score every node of a 2-action tree at once, or (PUCT)
+    keep the whole tree in registers, one node per lane; the arithmetic is the same as the global-memory,
+    level-by-level kernel, so whole trees must be equal bit for bit - also when the fused search takes over
+    after a few stepped simulations, with two players, and with some root actions illegal."""
     from muzero_amd.engine import SearchEngine
     z, net = load_net('mlp_cartpole')
     packed = pack_network(net)
     B, A, S = 96, 2, 50
     rng = np.random.default_rng(8)
-    cfg = make_config(gumbel, A, S, 1, 0.997)
+    cfg = make_config(gumbel, A, S, 2, 0.997)
     obs, logits, hidden, value = _roots(net, B, (1, 1, 4), rng)
-    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    legal, tp = np.ones((B, A)), rng.integers(0, 2, size=B).astype(np.int32)
+    legal[1::7, 0] = 0
+    legal[3::7, 1] = 0
     g = rng.gumbel(size=(B, A)) if gumbel else None
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     gnet = MuZeroNetwork(net_config('mlp_cartpole'), net.state_dict()).to('cuda')
     for stepped in (0, 7):
         out = []
-        for flag in ('0', '1'):
+        for flag, reg in (('0', '0'), ('1', '0'), ('1', '1')):   # global memory, LDS, registers
             monkeypatch.setenv('MZ_TREE_LDS', flag)
+            monkeypatch.setenv('MZ_TREE_REG', reg)
             eng = SearchEngine(cfg, packed.H, B, seed=13, lanes_per_tree=64)
             eng.set_network(packed)
             prior = eng.root_prepare(logits, legal, di, 0.25)
@@ -119,11 +123,12 @@ def test_lds_resident_tree_is_bit_identical(gumbel, monkeypatch):
             nv, calls = eng.stats()
             out.append(([eng.export_tree(b) for b in range(0, B, 5)], nv.cpu().numpy().copy(), calls.cpu().numpy().copy()))
             eng.close()
-        for t0, t1 in zip(out[0][0], out[1][0]):
-            for k in t0:
-                np.testing.assert_array_equal(t0[k], t1[k], err_msg=k)
-        np.testing.assert_array_equal(out[0][1], out[1][1])
-        np.testing.assert_array_equal(out[0][2], out[1][2])
+        for other in out[1:]:
+            for t0, t1 in zip(out[0][0], other[0]):
+                for k in t0:
+                    np.testing.assert_array_equal(t0[k], t1[k], err_msg=k)
+            np.testing.assert_array_equal(out[0][1], other[1])
+            np.testing.assert_array_equal(out[0][2], other[2])
 
 
 def test_network_too_large_for_lds_is_rejected():
