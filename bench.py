@@ -237,6 +237,9 @@ def main():
     sims = world * B * S * args.steps
     nv_all = mzdist.sum_over_ranks(node_visits, mzdist.reduce_device(dev))
 
+    # small batches of 2-action PUCT trees (<= 64 nodes) run with the tree in registers (csrc/search_reg.h)
+    reg_tree = (leaf == 'mlp' and not gumbel and A == 2 and S + 1 <= 64 and B <= 1024 and
+                os.environ.get('MZ_TREE_REG', '1') != '0')
     traffic = None
     try:  # HBM bytes per launch from the PMC counters, measured offline with rocprofv3 (profiles/hbm_traffic.json)
         with open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')) as f:
@@ -253,7 +256,7 @@ def main():
         'node_visits_per_sec': nv_all * args.steps / elapsed,
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
         'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
-        'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
+        'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
                                 'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -1,6 +1,6 @@
 """Soak test (not part of the suite): the whole-search kernel with in-kernel leaf evaluation on random MLP
 networks.  (1) Trees kept in LDS (with all-nodes selection for 2 actions, register-cached rows, the wave
-epilogue) must equal the global-memory path bit for bit; (2) every group width must agree with the CPU
+epilogue) or in registers must equal the global-memory path bit for bit; (2) every group width must agree with the CPU
 checker's search through the same lowered network on (nearly) every tree.
 
     python scripts/soak_fused_net.py [seed=1] [trials=60]
@@ -23,7 +23,7 @@ TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rng = np.random.default_rng(SEED)
 bad = 0
 for trial in range(TRIALS):
-    gumbel = bool(rng.integers(2)); A = int(rng.integers(2, 7)); S = int(rng.integers(1, 70)); players = int(rng.integers(1, 3))
+    gumbel = bool(rng.integers(2)); A = int(rng.choice([2, 2, 2, 3, 4, 6])); S = int(rng.integers(1, 70)); players = int(rng.integers(1, 3))
     gamma = float(rng.choice([1.0, 0.997])); B = int(rng.integers(1, 300))
     obs_n = int(rng.integers(2, 9)); enc = int(rng.choice([4, 8, 12, 16, 24])); L = int(rng.choice([1, 5, 10, 20]))
     lay = lambda: [int(rng.choice([8, 16, 32]))] * int(rng.integers(0, 2))  # noqa: E731
@@ -36,7 +36,9 @@ for trial in range(TRIALS):
     obs = rng.uniform(-1, 1, size=(B, 1, 1, obs_n)).astype(np.float32)
     logits, hidden, value = net.initial_inference(torch.as_tensor(obs))
     logits, hidden, value = logits.numpy(), hidden.numpy().reshape(B, -1), value.numpy()
-    legal = np.ones((B, A)); tp = rng.integers(0, players, size=B).astype(np.int32)
+    legal = np.ones((B, A))
+    if rng.integers(2): legal[np.arange(B), rng.integers(0, A, size=B)] = rng.integers(0, 2, size=B)   # some roots with one illegal action
+    tp = rng.integers(0, players, size=B).astype(np.int32)
     g = rng.gumbel(size=(B, A)) if gumbel else None
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     ref = orc.search_batch_net(cfg, packed, logits, hidden, value, legal, tp, dirichlet=di, frac=0.25, gumbel=g, seed=trial,
@@ -44,8 +46,9 @@ for trial in range(TRIALS):
     rl = 2
     while rl < A: rl *= 2
     ok, runs = True, {}
-    for lanes, lds in [(64, '0'), (64, '1')] + [(w, '1') for w in sorted({rl, 16}) if w >= rl]:
+    for lanes, lds, reg in [(64, '0', '0'), (64, '1', '0'), (64, '1', '1')] + [(w, '1', '0') for w in sorted({rl, 16}) if w >= rl]:
         os.environ['MZ_TREE_LDS'] = lds
+        os.environ['MZ_TREE_REG'] = reg     # trees in registers (2-action PUCT trees of at most 64 nodes)
         eng = SearchEngine(cfg, packed.H, B, seed=trial, lanes_per_tree=lanes)
         try:
             eng.set_network(packed)
@@ -58,21 +61,22 @@ for trial in range(TRIALS):
         action, rv, probs, _ = eng.to_act(0.0)
         nv, calls = eng.stats()
         trees = [eng.export_tree(b) for b in range(0, B, max(1, B // 6))]
-        runs[(lanes, lds)] = (action.cpu().numpy().copy(), rv.cpu().numpy().copy(), nv.cpu().numpy().copy(), trees)
+        runs[(lanes, lds, reg)] = (action.cpu().numpy().copy(), rv.cpu().numpy().copy(), nv.cpu().numpy().copy(), trees)
         frac_same = float((nv.cpu().numpy() == ref.node_visits).mean())
         close = float((np.abs(rv.cpu().numpy() - ref.root_value) < 1e-5).mean())
         if frac_same < 0.97 or close < 0.97:
             ok = False
-            print('CHECKER DISAGREES trial', trial, (lanes, lds), 'same visits %.3f close values %.3f' % (frac_same, close), flush=True)
+            print('CHECKER DISAGREES trial', trial, (lanes, lds, reg), 'same visits %.3f close values %.3f' % (frac_same, close), flush=True)
         eng.close()
-    if (64, '0') in runs and (64, '1') in runs:
-        a, b = runs[(64, '0')], runs[(64, '1')]
+    for other in ((64, '1', '0'), (64, '1', '1')):
+        if (64, '0', '0') not in runs or other not in runs: continue
+        a, b = runs[(64, '0', '0')], runs[other]
         same = all(np.array_equal(a[i], b[i]) for i in range(3))
         for ta, tb in zip(a[3], b[3]):
             same = same and all(np.array_equal(ta[k], tb[k]) for k in ta)
         if not same:
             ok = False
-            print('LDS PATH DIFFERS trial', trial, dict(gumbel=gumbel, A=A, S=S, B=B, enc=enc, L=L), flush=True)
+            print('LDS / REGISTER PATH DIFFERS trial', trial, other, dict(gumbel=gumbel, A=A, S=S, B=B, enc=enc, L=L), flush=True)
     bad += not ok
     if trial % 10 == 0: print('trial', trial, dict(gumbel=gumbel, A=A, S=S, B=B, enc=enc, L=L, widths=sorted(runs)), flush=True)
 print('done, failing trials:', bad)
