@@ -46,6 +46,7 @@ struct mz_ctx {
     NetDev net;         // uploaded dense-program network (mz_set_network)
     int net_scratch;    // activation floats per tree
     bool net_small;     // the program fits the register-cached evaluator and the whole-wave epilogue
+    bool net_tiny;      // ... and its hidden states and second-level outputs can live in registers (search_reg.h)
     void *net_meta_d, *net_data_d;
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
@@ -126,7 +127,7 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     c->cfg.c_table_h = nullptr;
     c->lanes = lanes;
     c->n_expanded = 0; c->selected = 0; c->B = 0;
-    memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_small = false; c->net_meta_d = c->net_data_d = nullptr;
+    memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_small = false; c->net_tiny = false; c->net_meta_d = c->net_data_d = nullptr;
     memset(&c->root, 0, sizeof c->root); memset(c->root_bufs, 0, sizeof c->root_bufs);
     memset(&c->mnet, 0, sizeof c->mnet); memset(c->mnet_bufs, 0, sizeof c->mnet_bufs);
     Dev &d = c->d;
@@ -408,16 +409,19 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
         if (const char *e = getenv("MZ_TREE_LDS")) tree_in_lds = tree_in_lds && atoi(e) != 0;
         hipError_t attr_err = hipSuccess;
         // 2-action PUCT trees of at most 64 nodes served by whole waves: the tree lives in registers
-        const int hid_bytes = (L.N * L.H * 4 + 15) & ~15;
+        bool tiny = c->net_tiny;
+        if (const char *e = getenv("MZ_NET_TINY")) tiny = tiny && atoi(e) != 0;
+        const int hid_bytes = tiny ? 0 : (L.N * L.H * 4 + 15) & ~15;
         const size_t lds_reg = ((lds + 15) & ~(size_t)15) + (size_t)gpb * hid_bytes;
         bool tree_in_regs = c->lanes == 64 && !c->cfg.gumbel && L.A == 2 && L.N <= 64 && c->net_small && !L.prior_f32 &&
                             lds_reg + (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8 <= 160 * 1024;
         if (const char *e = getenv("MZ_TREE_REG")) tree_in_regs = tree_in_regs && atoi(e) != 0;
         if (tree_in_regs) {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_reg),
+            auto kern = !tiny ? k_search_reg<0> : L.H == 8 ? k_search_reg<8> : k_search_reg<4>;
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
             if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
-            hipLaunchKernelGGL(k_search_reg, dim3(n_blocks), dim3(n_threads), lds_reg, (hipStream_t)stream, c->d, c->net,
+            hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(n_threads), lds_reg, (hipStream_t)stream, c->d, c->net,
                                c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch, hid_bytes);
             c->n_expanded += n_sims;
             return launch_status("mz_search_run");
@@ -712,6 +716,27 @@ extern "C" int mz_set_network(mz_ctx *c, const int32_t *meta_h, int32_t n_meta, 
     c->net_small = meta_h[0] <= 2 && io_h[10] == 1 && io_h[6] <= 16 && io_h[9] <= 32;
     for (int l = 0; l < meta_h[0]; l++)
         if (lv[4 * l] > 64 || lv[4 * l + 1] > 16) c->net_small = false;
+    // hidden states in registers: two levels without residual inputs, every first-level row reads the network
+    // input (hidden state, then the encoded action), the second level produces exactly the four outputs
+    const int H = io_h[6], A = io_h[7], asz = io_h[8], sup = io_h[9];
+    bool tiny = c->net_small && meta_h[0] == 2 && (H == 4 || H == 8) && A == 2 && asz == 2 && sup <= 24 && io_h[1] == io_h[0] + H &&
+                lv[4] == H + 2 * sup + A;
+    if (tiny) {
+        for (int r = 0; r < lv[0]; r++) {
+            const int32_t *d = rows + 4 * (lv[3] + r);
+            if (d[0] != io_h[0] || d[3] >= 0) tiny = false;
+        }
+        int seen = 0;
+        for (int r = 0; r < lv[4]; r++) {
+            const int32_t *d = rows + 4 * (lv[7] + r);
+            if (d[3] >= 0) tiny = false;
+            const int y = d[1];
+            seen += (y >= io_h[2] && y < io_h[2] + H) + (y >= io_h[3] && y < io_h[3] + sup) + (y >= io_h[4] && y < io_h[4] + A) +
+                    (y >= io_h[5] && y < io_h[5] + sup);
+        }
+        if (seen != lv[4]) tiny = false;
+    }
+    c->net_tiny = tiny;
     return MZ_OK;
 }
 

@@ -8,9 +8,12 @@
 //    new mean reaches its parent's lane with one cross-lane read;
 //  * expansion (mcts/mcts.py:116-141) is a predicated register write in the leaf's and the parent's lanes.
 // Small batches are bound by the latency of one wave's dependent instructions and LDS round trips, not by
-// bandwidth; this form removes nearly all LDS traffic of the tree.  Hidden states stay in LDS, the
-// network is evaluated exactly as in k_search_net (register-cached weights, wave epilogue).  Every
-// expression is the one the lane-group kernels evaluate (tree_ops.h), so trees are identical bit for bit.
+// bandwidth; this form removes nearly all LDS traffic of the tree.  The network is evaluated as in
+// k_search_net (register-cached weights, wave epilogue) with hidden states in LDS, or, for the smallest
+// networks (TINY), with the hidden states in registers too: the parent's state reaches the first level as
+// wave-uniform operands (lane reads), the second level's rows are placed on the lanes where the epilogue
+// wants their outputs, and only the hand-over between the two levels goes through LDS.  Every expression is
+// the one the lane-group kernels evaluate (tree_ops.h, dense_net.h), so trees are identical bit for bit.
 #pragma once
 #include "search_net.h"
 
@@ -27,6 +30,15 @@ __device__ __forceinline__ double lane_read(double v, int lane)  // lane: wave-u
 // activation scratch | per-wave hidden states [N][H] (`hid_bytes` each, 16-byte aligned).
 // Requires (checked by the host): PUCT, A == 2, N <= 64, a program dense_run_cached serves, one
 // normalisation group of at most 16 hidden values and supports of at most 32 bins.
+// TINY (HT = hidden size, 4 or 8; 0 = not TINY) additionally: two levels without residual inputs, every
+// first-level row reads the network input (hidden state followed by the 2-value one-hot action), supports
+// of at most 24 bins and the second level produces exactly the four outputs (then no LDS is reserved for
+// hidden states).  The hidden size is a template parameter so that the input vector's layout is static.
+// Lane placement of the second level's rows under TINY: value logit i on lane i, next hidden state k on
+// lane 24 + k, reward logit i on lane 32 + i, policy logit a on lane 56 + a.
+#define MZ_TINY_HID 24
+#define MZ_TINY_POL 56
+template <int HT>
 __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int first_leaf, int n_sims,
                                                           const double *noise, int noise_max_calls,
                                                           int scratch_floats, int hid_bytes)
@@ -35,6 +47,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
     float *w = lds;
     int32_t *meta = reinterpret_cast<int32_t *>(lds + net.n_data);
     float *scratch0 = lds + net.n_data + net.n_meta;
+    constexpr bool TINY = HT > 0;
     const int n_threads = blockDim.x, waves_per_block = n_threads / 64;
     const int wv = threadIdx.x / 64, lane = threadIdx.x % 64;
     for (int i = threadIdx.x; i < net.n_data; i += n_threads) w[i] = net.data[i];
@@ -48,13 +61,24 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
     __syncthreads();
     const int t = (int)blockIdx.x * waves_per_block + wv;
     if (t >= d.B) return;
-    const int H = d.L.H, S = d.L.S;
+    const int H = TINY ? HT : d.L.H, S = d.L.S;
     size_t base = ((size_t)(net.n_data + net.n_meta) + (size_t)waves_per_block * scratch_floats) * 4;
     base = (base + 15) & ~(size_t)15;
     float *hid = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + base + (size_t)wv * hid_bytes);
     float *const hid_global = d.hidden + (long long)t * d.L.N * H;
     const TreeMem mg = tree_mem(d, t);
-    for (int i = lane; i < first_leaf * H; i += 64) hid[i] = hid_global[i];
+    constexpr int HR = TINY ? HT : 1;
+    float hreg[HR];  // TINY: this lane's node's hidden state
+#pragma unroll
+    for (int k = 0; k < HR; k++) hreg[k] = 0.0f;
+    if constexpr (TINY) {
+        if (lane < first_leaf) {
+#pragma unroll
+            for (int k = 0; k < HT; k++) hreg[k] = hid_global[lane * HT + k];
+        }
+    } else {
+        for (int i = lane; i < first_leaf * H; i += 64) hid[i] = hid_global[i];
+    }
 
     // ---- this lane's node
     int nv = 0, par = -1, afp = -1, tp = 0, dep = 0;
@@ -85,6 +109,31 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
     const int asz = net.io[8], sup = net.io[9];
     DenseRegs<2, 4> regs;
     dense_cache_load<64, 2, 4>(meta, w, lane, regs);
+    if constexpr (TINY) {
+        // second level: this lane takes the row whose output the epilogue wants here (or none)
+        const int32_t *lv = meta + meta[5], *rows = meta + meta[6];
+        const int n_rows2 = lv[4], row0 = lv[7];
+        const float4 *W4 = reinterpret_cast<const float4 *>(w + lv[6]);
+        int tgt = -1;
+        if (lane < sup) tgt = net.io[5] + lane;
+        else if (lane >= MZ_TINY_HID && lane < MZ_TINY_HID + H) tgt = net.io[2] + lane - MZ_TINY_HID;
+        else if (lane >= 32 && lane < 32 + sup) tgt = net.io[3] + lane - 32;
+        else if (lane >= MZ_TINY_POL && lane < MZ_TINY_POL + 2) tgt = net.io[4] + lane - MZ_TINY_POL;
+        int mine = -1;
+        for (int r = 0; r < n_rows2; r++)
+            if (rows[4 * (row0 + r) + 1] == tgt) mine = r;
+        regs.ds[1] = make_int4(0, -1, 0, -1);
+        regs.bias[1] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) regs.w[1][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mine >= 0) {
+            regs.ds[1] = *reinterpret_cast<const int4 *>(rows + 4 * (row0 + mine));
+            regs.bias[1] = (w + meta[4])[row0 + mine];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < regs.k4n[1]) regs.w[1][k] = W4[k * n_rows2 + mine];
+        }
+    }
     lds_fence();
 #ifdef MZ_STAMPS
     long long st_sel = 0, st_net = 0, st_epi = 0, st_bk = 0, st_in = 0, st_mm = 0, st_t;
@@ -146,20 +195,104 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         MZ_STAMP(st_sel)
 #endif
         // ---- leaf evaluation: the PARENT's hidden state and the encoded action (mcts/mcts.py:240-243)
-        const float *ph = hid + parent * H;
-        for (int i = lane; i < H; i += 64) sc[net.io[0] + i] = ph[i];
-        for (int i = lane; i < asz; i += 64) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
-        lds_fence();
-#ifdef MZ_STAMPS
-        MZ_STAMP(st_in)
-#endif
-        dense_run_cached<2, 4>(regs, sc);
-#ifdef MZ_STAMPS
-        MZ_STAMP(st_net)
-#endif
         double value, reward;
-        epilogue_wave_small(sc + net.io[2], H, sc + net.io[5], sc + net.io[3], sup, lane, hid + leaf * H, &value, &reward);
-        const float lg0 = sc[net.io[4]], lg1 = sc[net.io[4] + 1];
+        float lg0, lg1;
+        if constexpr (TINY) {
+            // network input as wave-uniform values: x[k] = hidden[k] (k < HT), then the one-hot action, then zeros
+            float x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < HT) x[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[k < HT ? k : 0]), parent));
+                else x[k] = (k - HT < 2 && k - HT == action) ? 1.0f : 0.0f;
+            }
+#ifdef MZ_STAMPS
+            MZ_STAMP(st_in)
+#endif
+            {   // first level: this lane's row, same multiply-add order as dense_run
+                const int4 ds = regs.ds[0];
+                float acc = regs.bias[0];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < regs.k4n[0]) {
+                        const float4 wv = regs.w[0][k];
+                        acc = fmaf(wv.x, x[4 * k], acc);
+                        acc = fmaf(wv.y, x[4 * k + 1], acc);
+                        acc = fmaf(wv.z, x[4 * k + 2], acc);
+                        acc = fmaf(wv.w, x[4 * k + 3], acc);
+                    }
+                }
+                if (ds.z == 1) acc = acc > 0.0f ? acc : 0.0f;
+                else if (ds.z == 2) acc = acc > 0.0f ? acc : expm1f(acc);
+                if (ds.y >= 0) sc[ds.y] = acc;
+            }
+            lds_fence();
+            float out2 = 0.0f;
+            {   // second level: output stays in this lane
+                const int4 ds = regs.ds[1];
+                if (ds.y >= 0) {
+                    const float4 *x4 = reinterpret_cast<const float4 *>(sc + ds.x);
+                    float acc = regs.bias[1];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k < regs.k4n[1]) {
+                            const float4 wv = regs.w[1][k], xv = x4[k];
+                            acc = fmaf(wv.x, xv.x, acc);
+                            acc = fmaf(wv.y, xv.y, acc);
+                            acc = fmaf(wv.z, xv.z, acc);
+                            acc = fmaf(wv.w, xv.w, acc);
+                        }
+                    }
+                    if (ds.z == 1) acc = acc > 0.0f ? acc : 0.0f;
+                    else if (ds.z == 2) acc = acc > 0.0f ? acc : expm1f(acc);
+                    out2 = acc;
+                }
+            }
+            lds_fence();
+#ifdef MZ_STAMPS
+            MZ_STAMP(st_net)
+#endif
+            // epilogue_wave_small on registers: value logits on lanes 0.., reward logits on lanes 32.., the raw
+            // next hidden state on lanes MZ_TINY_HID.. (min / max are exact, so the lanes they sit on do not matter)
+            const float finf = __builtin_huge_valf();
+            const bool up = lane >= 32, has_h = lane >= MZ_TINY_HID && lane < MZ_TINY_HID + H;
+            const int i = lane & 31, Ls = (sup - 1) / 2;
+            const float v = i < sup ? out2 : -finf;
+            const float r = has_h ? out2 : 0.0f;
+            constexpr int W = HT <= 2 ? 2 : HT <= 4 ? 4 : 8;
+            const float mn = gminf<16>(has_h ? r : finf, W), mx = gmaxf<16>(has_h ? r : -finf, W);
+            const float m = half_reduce(v, -finf, up, [](float p, float q) { return q > p ? q : p; });
+            const float den = (mx - mn) + 1e-5f;
+            const float e = i < sup ? expf(v - m) : 0.0f;
+            const float hv = (r - mn) / den;
+            const float sum = half_reduce(e, 0.0f, up, [](float p, float q) { return p + q; });
+            double xs = i < sup ? (double)(e / sum) * (double)(i - Ls) : 0.0;
+            xs = half_reduce(xs, 0.0, up, [](double p, double q) { return p + q; });
+            const double y = inv_value_transform(xs);
+            value = wave_lane(y, 0);
+            reward = wave_lane(y, 32);
+#pragma unroll
+            for (int k = 0; k < HT; k++) {
+                const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), MZ_TINY_HID + k));
+                hreg[k] = lane == leaf ? hk : hreg[k];
+            }
+            lg0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out2), MZ_TINY_POL));
+            lg1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out2), MZ_TINY_POL + 1));
+        } else {
+            const float *ph = hid + parent * H;
+            for (int i = lane; i < H; i += 64) sc[net.io[0] + i] = ph[i];
+            for (int i = lane; i < asz; i += 64) sc[net.io[1] + i] = i == action ? 1.0f : 0.0f;
+            lds_fence();
+#ifdef MZ_STAMPS
+            MZ_STAMP(st_in)
+#endif
+            dense_run_cached<2, 4>(regs, sc);
+#ifdef MZ_STAMPS
+            MZ_STAMP(st_net)
+#endif
+            epilogue_wave_small(sc + net.io[2], H, sc + net.io[5], sc + net.io[3], sup, lane, hid + leaf * H, &value, &reward);
+            lg0 = sc[net.io[4]];
+            lg1 = sc[net.io[4] + 1];
+        }
 #ifdef MZ_STAMPS
         MZ_STAMP(st_mm)
 #endif
@@ -211,7 +344,14 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         double *pp = reinterpret_cast<double *>(rv.prior);
         pp[0] = pr0; pp[1] = pr1; rv.crew[0] = r0; rv.crew[1] = r1; rv.cval[0] = v0; rv.cval[1] = v1;
     }
-    for (int i = lane; i < live * H; i += 64) hid_global[i] = hid[i];
+    if constexpr (TINY) {
+        if (lane < live) {
+#pragma unroll
+            for (int k = 0; k < HT; k++) hid_global[lane * HT + k] = hreg[k];
+        }
+    } else {
+        for (int i = lane; i < live * H; i += 64) hid_global[i] = hid[i];
+    }
 #ifdef MZ_STAMPS
     if (lane == 0) {
         long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);

@@ -25,7 +25,7 @@ bad = 0
 for trial in range(TRIALS):
     gumbel = bool(rng.integers(2)); A = int(rng.choice([2, 2, 2, 3, 4, 6])); S = int(rng.integers(1, 70)); players = int(rng.integers(1, 3))
     gamma = float(rng.choice([1.0, 0.997])); B = int(rng.integers(1, 300))
-    obs_n = int(rng.integers(2, 9)); enc = int(rng.choice([4, 8, 12, 16, 24])); L = int(rng.choice([1, 5, 10, 20]))
+    obs_n = int(rng.integers(2, 9)); enc = int(rng.choice([2, 4, 6, 8, 8, 12, 16, 24])); L = int(rng.choice([1, 5, 10, 20]))
     lay = lambda: [int(rng.choice([8, 16, 32]))] * int(rng.integers(0, 2))  # noqa: E731
     ncfg = SimpleNamespace(network='mlp', observation_dim=[1, 1, obs_n], n_actions=A, n_stacked_observations=1, encoding_size=enc,
                            fc_reward_layers=lay() or [16], fc_policy_layers=lay() or [16], fc_value_layers=lay() or [16],
@@ -46,9 +46,10 @@ for trial in range(TRIALS):
     rl = 2
     while rl < A: rl *= 2
     ok, runs = True, {}
-    for lanes, lds, reg in [(64, '0', '0'), (64, '1', '0'), (64, '1', '1')] + [(w, '1', '0') for w in sorted({rl, 16}) if w >= rl]:
+    for lanes, lds, reg in [(64, '0', '0'), (64, '1', '0'), (64, '1', '1'), (64, '1', 'lds-hidden')] + [(w, '1', '0') for w in sorted({rl, 16}) if w >= rl]:
         os.environ['MZ_TREE_LDS'] = lds
-        os.environ['MZ_TREE_REG'] = reg     # trees in registers (2-action PUCT trees of at most 64 nodes)
+        os.environ['MZ_TREE_REG'] = '0' if reg == '0' else '1'     # trees in registers (2-action PUCT trees of at most 64 nodes)
+        os.environ['MZ_NET_TINY'] = '0' if reg == 'lds-hidden' else '1'   # ... with the hidden states in registers too
         eng = SearchEngine(cfg, packed.H, B, seed=trial, lanes_per_tree=lanes)
         try:
             eng.set_network(packed)
@@ -68,7 +69,7 @@ for trial in range(TRIALS):
             ok = False
             print('CHECKER DISAGREES trial', trial, (lanes, lds, reg), 'same visits %.3f close values %.3f' % (frac_same, close), flush=True)
         eng.close()
-    for other in ((64, '1', '0'), (64, '1', '1')):
+    for other in ((64, '1', '0'), (64, '1', '1'), (64, '1', 'lds-hidden')):
         if (64, '0', '0') not in runs or other not in runs: continue
         a, b = runs[(64, '0', '0')], runs[other]
         same = all(np.array_equal(a[i], b[i]) for i in range(3))

@@ -108,9 +108,11 @@ def test_lds_resident_tree_is_bit_identical(gumbel, monkeypatch):
     gnet = MuZeroNetwork(net_config('mlp_cartpole'), net.state_dict()).to('cuda')
     for stepped in (0, 7):
         out = []
-        for flag, reg in (('0', '0'), ('1', '0'), ('1', '1')):   # global memory, LDS, registers
+        # trees in global memory, in LDS, in registers (hidden states in LDS), in registers with hidden states too
+        for flag, reg, tiny in (('0', '0', '0'), ('1', '0', '0'), ('1', '1', '0'), ('1', '1', '1')):
             monkeypatch.setenv('MZ_TREE_LDS', flag)
             monkeypatch.setenv('MZ_TREE_REG', reg)
+            monkeypatch.setenv('MZ_NET_TINY', tiny)
             eng = SearchEngine(cfg, packed.H, B, seed=13, lanes_per_tree=64)
             eng.set_network(packed)
             prior = eng.root_prepare(logits, legal, di, 0.25)
