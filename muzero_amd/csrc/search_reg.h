@@ -93,10 +93,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         const double *pp = reinterpret_cast<const double *>(rv.prior);
         pr0 = pp[0]; pr1 = pp[1]; r0 = rv.crew[0]; r1 = rv.crew[1]; v0 = rv.cval[0]; v1 = rv.cval[1];
     }
+    int maxdep = 0;  // depth of the deepest node so far (wave-uniform)
     for (int n = 1; n < first_leaf; n++) {  // parents precede their children: one forward sweep gives every depth
         const int p = __builtin_amdgcn_readlane(par, n);
         const int dp = __builtin_amdgcn_readlane(dep, p) + 1;
         dep = lane == n ? dp : dep;
+        maxdep = dp > maxdep ? dp : maxdep;
     }
 
     const double inf = __builtin_huge_val();
@@ -142,14 +144,25 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
     for (int s = 0; s < n_sims; s++) {
         const int leaf = first_leaf + s;
         // ---- selection at every node (this lane: its node, both actions)
-        const uint32_t call = calls + (uint32_t)dep;
+        // tie-break noise of selection call (calls + depth) for both actions: the same for every node of a
+        // depth, so lane l draws the value of (depth l / 2, action l % 2) and each node fetches its pair
         double u0 = 0.0, u1 = 0.0;
         if (d.noise_mode == 0) {
-            u0 = noise_from_key(key, call, 0u);
-            u1 = noise_from_key(key, call, 1u);
-        } else if (d.noise_mode == 1 && (int)call < noise_max_calls) {
-            u0 = nz[(long long)call * 2];
-            u1 = nz[(long long)call * 2 + 1];
+            if (maxdep < 32) {
+                const double ul = noise_from_key(key, calls + (uint32_t)(lane >> 1), (unsigned)(lane & 1));
+                u0 = __shfl(ul, 2 * dep, 64);
+                u1 = __shfl(ul, 2 * dep + 1, 64);
+            } else {
+                const uint32_t call = calls + (uint32_t)dep;
+                u0 = noise_from_key(key, call, 0u);
+                u1 = noise_from_key(key, call, 1u);
+            }
+        } else if (d.noise_mode == 1) {
+            const uint32_t call = calls + (uint32_t)dep;
+            if ((int)call < noise_max_calls) {
+                u0 = nz[(long long)call * 2];
+                u1 = nz[(long long)call * 2 + 1];
+            }
         }
         const double q0 = r0 + d.discount * v0, q1 = r1 + d.discount * v1;
         const double s0 = cv0 > 0 ? q0 : nval, s1 = cv1 > 0 ? q1 : nval;
@@ -175,19 +188,18 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         const int chosen_child = best ? ci1 : ci0;
         const int pack = ((chosen_child + 1) << 8) | best;
         // ---- descent: follow the decisions from the root
-        int node = 0, depth = 0, ntp = 0, action = 0, pathreg = 0;
+        int node = 0, depth = 0, pk;
         unsigned long long onpath = 0ull;
         while (true) {
-            const int pk = __builtin_amdgcn_readlane(pack, node);
-            action = pk & 0xff;
+            pk = __builtin_amdgcn_readlane(pack, node);
             const int child = (pk >> 8) - 1;
             onpath |= 1ull << node;
-            pathreg = lane == depth ? node : pathreg;  // lane i: the path's node at depth i
-            ntp = d.players == 1 ? ntp : 1 - ntp;
             depth++;
             if (child < 0 || child >= leaf || depth > S) break;
             node = child;
         }
+        const int action = pk & 0xff;
+        const int ntp = d.players == 1 ? 0 : (depth & 1);  // starts at player 0, flips once per level (mcts/mcts.py:105,112)
         const int parent = node;
         calls += (uint32_t)depth;
         visited += depth + 1;
@@ -300,11 +312,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         // L_i with L_0 = value, L_{i+1} = reward_i + gamma L_i (reward_0 = the new edge's reward).
         double L = value, myL = 0.0;
         const double rsel = best ? r1 : r0;  // reward of the edge this node's decision follows
-        for (int i = 0; i < depth; i++) {
-            const int nd = __builtin_amdgcn_readlane(pathreg, depth - 1 - i);
+        for (int i = 0, nd = parent; i < depth; i++) {
             myL = lane == nd ? L : myL;
             const double ri = i == 0 ? reward : lane_read(rsel, nd);
             L = ri + d.discount * L;
+            nd = __builtin_amdgcn_readlane(par, nd);  // up one level (the root's -1 ends the walk with the loop)
         }
         const bool onp = (onpath >> lane) & 1ull;
         const double newV = (nval * (double)nv + (tp == ntp ? myL : -myL)) / (double)(nv + 1);
@@ -324,6 +336,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
             cv0 = 0; cv1 = 0; ci0 = -1; ci1 = -1;
             pr0 = (double)lg0; pr1 = (double)lg1; r0 = 0.0; r1 = 0.0; v0 = 0.0; v1 = 0.0;
         }
+        maxdep = depth > maxdep ? depth : maxdep;
         lds_fence();
 #ifdef MZ_STAMPS
         MZ_STAMP(st_bk)
