@@ -148,14 +148,15 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         // depth, so lane l draws the value of (depth l / 2, action l % 2) and each node fetches its pair
         double u0 = 0.0, u1 = 0.0;
         if (d.noise_mode == 0) {
-            if (maxdep < 32) {
-                const double ul = noise_from_key(key, calls + (uint32_t)(lane >> 1), (unsigned)(lane & 1));
-                u0 = __shfl(ul, 2 * dep, 64);
-                u1 = __shfl(ul, 2 * dep + 1, 64);
-            } else {
-                const uint32_t call = calls + (uint32_t)dep;
-                u0 = noise_from_key(key, call, 0u);
-                u1 = noise_from_key(key, call, 1u);
+            const double ul = noise_from_key(key, calls + (uint32_t)(lane >> 1), (unsigned)(lane & 1));
+            u0 = __shfl(ul, 2 * dep, 64);
+            u1 = __shfl(ul, 2 * dep + 1, 64);
+            if (maxdep >= 32) {  // a second page of draws for nodes 32 and more levels down (rare)
+                asm volatile("; deep tree" ::: "memory");  // keeps the compiler from evaluating this page speculatively
+                const double uh = noise_from_key(key, calls + 32u + (uint32_t)(lane >> 1), (unsigned)(lane & 1));
+                const double h0 = __shfl(uh, 2 * (dep - 32), 64), h1 = __shfl(uh, 2 * (dep - 32) + 1, 64);
+                u0 = dep >= 32 ? h0 : u0;
+                u1 = dep >= 32 ? h1 : u1;
             }
         } else if (d.noise_mode == 1) {
             const uint32_t call = calls + (uint32_t)dep;
@@ -192,11 +193,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         unsigned long long onpath = 0ull;
         while (true) {
             pk = __builtin_amdgcn_readlane(pack, node);
-            const int child = (pk >> 8) - 1;
             onpath |= 1ull << node;
             depth++;
-            if (child < 0 || child >= leaf || depth > S) break;
-            node = child;
+            const unsigned child = (unsigned)(pk >> 8) - 1u;  // no child: 0xffffffff
+            if (child >= (unsigned)leaf || depth > S) break;  // depth bound: a malformed tree cannot spin forever
+            node = (int)child;
         }
         const int action = pk & 0xff;
         const int ntp = d.players == 1 ? 0 : (depth & 1);  // starts at player 0, flips once per level (mcts/mcts.py:105,112)

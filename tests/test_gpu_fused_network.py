@@ -87,14 +87,18 @@ def test_fused_equals_step_mode_with_torch_network():
     eng.close()
 
 
-@pytest.mark.parametrize('gumbel', [False, True])
-def test_lds_resident_tree_is_bit_identical(gumbel, monkeypatch):
+@pytest.mark.parametrize('gumbel,deep', [(False, False), (True, False), (False, True)])
+def test_lds_resident_tree_is_bit_identical(gumbel, deep, monkeypatch):
     """Small batches keep their trees in LDS and score every node of a 2-action tree at once, or (PUCT)
     keep the whole tree in registers, one node per lane; the arithmetic is the same as the global-memory,
     level-by-level kernel, so whole trees must be equal bit for bit - also when the fused search takes over
     after a few stepped simulations, with two players, and with some root actions illegal."""
     from muzero_amd.engine import SearchEngine
     z, net = load_net('mlp_cartpole')
+    if deep:   # a policy head that all but always prefers action 0: trees degenerate into chains 40+ levels deep
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd['prediction_network.policy_network.2.bias'][0] += 30.0
+        net = MuZeroNetwork(net_config('mlp_cartpole'), sd)
     packed = pack_network(net)
     B, A, S = 96, 2, 50
     rng = np.random.default_rng(8)
@@ -131,6 +135,8 @@ def test_lds_resident_tree_is_bit_identical(gumbel, monkeypatch):
                     np.testing.assert_array_equal(t0[k], t1[k], err_msg=k)
             np.testing.assert_array_equal(out[0][1], other[1])
             np.testing.assert_array_equal(out[0][2], other[2])
+        if deep:   # node visits per tree = sum of (leaf depth + 1): chains reach far beyond 32 levels
+            assert out[0][1].max() > S * 20
 
 
 def test_network_too_large_for_lds_is_rejected():
