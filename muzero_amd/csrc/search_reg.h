@@ -107,6 +107,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
     const bool legal0 = lane != 0 || (legal & 1ull), legal1 = lane != 0 || ((legal >> 1) & 1ull);
     const double *nz = noise ? noise + (long long)t * noise_max_calls * 2 : nullptr;
     uint32_t calls = d.noise_calls[t];
+    uint32_t wbase = calls - 64u;  // noise window: empty
+    double w0 = 0.0, w1 = 0.0;
     long long visited = 0;
     const int asz = net.io[8], sup = net.io[9];
     DenseRegs<2, 4> regs;
@@ -144,20 +146,20 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
     for (int s = 0; s < n_sims; s++) {
         const int leaf = first_leaf + s;
         // ---- selection at every node (this lane: its node, both actions)
-        // tie-break noise of selection call (calls + depth) for both actions: the same for every node of a
-        // depth, so lane l draws the value of (depth l / 2, action l % 2) and each node fetches its pair
+        // tie-break noise of selection call (calls + depth), both actions: the same for every node of a depth.
+        // Lane l keeps the draws of call (wbase + l); the window is redrawn when this simulation could run past it
+        // (a simulation uses up `depth` calls, so one window lasts about ten simulations).
         double u0 = 0.0, u1 = 0.0;
         if (d.noise_mode == 0) {
-            const double ul = noise_from_key(key, calls + (uint32_t)(lane >> 1), (unsigned)(lane & 1));
-            u0 = __shfl(ul, 2 * dep, 64);
-            u1 = __shfl(ul, 2 * dep + 1, 64);
-            if (maxdep >= 32) {  // a second page of draws for nodes 32 and more levels down (rare)
-                asm volatile("; deep tree" ::: "memory");  // keeps the compiler from evaluating this page speculatively
-                const double uh = noise_from_key(key, calls + 32u + (uint32_t)(lane >> 1), (unsigned)(lane & 1));
-                const double h0 = __shfl(uh, 2 * (dep - 32), 64), h1 = __shfl(uh, 2 * (dep - 32) + 1, 64);
-                u0 = dep >= 32 ? h0 : u0;
-                u1 = dep >= 32 ? h1 : u1;
+            if ((int)(calls - wbase) + maxdep > 63) {
+                asm volatile("; redraw the noise window" ::: "memory");  // not to be evaluated speculatively
+                wbase = calls;
+                w0 = noise_from_key(key, wbase + (uint32_t)lane, 0u);
+                w1 = noise_from_key(key, wbase + (uint32_t)lane, 1u);
             }
+            const int src = (int)(calls - wbase) + dep;
+            u0 = __shfl(w0, src, 64);
+            u1 = __shfl(w1, src, 64);
         } else if (d.noise_mode == 1) {
             const uint32_t call = calls + (uint32_t)dep;
             if ((int)call < noise_max_calls) {
@@ -167,17 +169,25 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         }
         const double q0 = r0 + d.discount * v0, q1 = r1 + d.discount * v1;
         const double s0 = cv0 > 0 ? q0 : nval, s1 = cv1 > 0 ? q1 : nval;
-        // min / max over the two actions as each action's lane of a 2-lane group computes them (np.min /
-        // np.max: a NaN wins)
-        double lo0 = (s1 < s0 || s1 != s1) ? s1 : s0, lo1 = (s0 < s1 || s0 != s0) ? s0 : s1;
-        double hi0 = (s1 > s0 || s1 != s1) ? s1 : s0, hi1 = (s0 > s1 || s0 != s0) ? s0 : s1;
-        lo0 = nval < lo0 ? nval : lo0; lo1 = nval < lo1 ? nval : lo1;
-        hi0 = nval > hi0 ? nval : hi0; hi1 = nval > hi1 ? nval : hi1;
-        double den0 = hi0 - lo0, den1 = hi1 - lo1;
-        den0 = den0 < 1e-8 ? 1e-8 : den0; den1 = den1 < 1e-8 ? 1e-8 : den1;
+        // min / max over the two actions (np.min / np.max: a NaN wins).  The 2-lane groups compute them per action
+        // lane with the operands swapped, which can only differ in the sign of a zero when the two compare equal -
+        // and that never reaches a decision: (cq - lo) is then +0 for the tied action either way
+        double lo0 = (s1 < s0 || s1 != s1) ? s1 : s0;
+        double hi0 = (s1 > s0 || s1 != s1) ? s1 : s0;
+        lo0 = nval < lo0 ? nval : lo0;
+        hi0 = nval > hi0 ? nval : hi0;
+        double den0 = hi0 - lo0;
+        den0 = den0 < 1e-8 ? 1e-8 : den0;
+        const double lo1 = lo0, den1 = den0;
         const double cq0 = cv0 > 0 ? q0 : lo0, cq1 = cv1 > 0 ? q1 : lo1;
         const double nq0 = (cq0 - lo0) / den0, nq1 = (cq1 - lo1) / den1;
-        const double cc = ct ? ct[nv] : d.c_table[nv];
+        double cc;
+        if (ct) {
+            cc = ct[nv];  // LDS
+        } else {
+            asm volatile("; exploration constants from global memory" ::: "memory");  // two typed loads, not one generic
+            cc = d.c_table[nv];
+        }
         const double sq0 = sqt ? sqt[nv * (S + 1) + cv0] : sqrt((double)nv / (double)(1 + cv0));
         const double sq1 = sqt ? sqt[nv * (S + 1) + cv1] : sqrt((double)nv / (double)(1 + cv1));
         const double uu0 = cc * pr0 + sq0, uu1 = cc * pr1 + sq1;
