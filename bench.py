@@ -168,6 +168,10 @@ def main():
     temperature = 1.0
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # small batches of 2-action PUCT trees (<= 64 nodes) run with the tree in registers (csrc/search_reg.h);
+    # that kernel also runs the final action rule, so search + rule are one launch
+    reg_tree = (leaf == 'mlp' and not gumbel and A == 2 and S + 1 <= 64 and B <= 1024 and
+                os.environ.get('MZ_TREE_REG', '1') != '0')
 
     def step(i=None):
         if leaf == 'dropin':
@@ -197,6 +201,11 @@ def main():
             eng.reset(prior, root_value, root_hidden, to_play, legal, gnoise, tree_id0=tree_id0)
         if i is not None:
             ev[i][0].record()
+        if leaf == 'mlp' and reg_tree:   # search + final action rule in one launch
+            out = eng.search_net_act(temperature, u)
+            if i is not None:
+                ev[i][1].record()
+            return out
         if leaf == 'mlp':
             eng.search_net()
         elif leaf == 'mfma':
@@ -237,9 +246,6 @@ def main():
     sims = world * B * S * args.steps
     nv_all = mzdist.sum_over_ranks(node_visits, mzdist.reduce_device(dev))
 
-    # small batches of 2-action PUCT trees (<= 64 nodes) run with the tree in registers (csrc/search_reg.h)
-    reg_tree = (leaf == 'mlp' and not gumbel and A == 2 and S + 1 <= 64 and B <= 1024 and
-                os.environ.get('MZ_TREE_REG', '1') != '0')
     traffic = None
     try:  # HBM bytes per launch from the PMC counters, measured offline with rocprofv3 (profiles/hbm_traffic.json)
         with open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')) as f:

@@ -176,6 +176,14 @@ int mz_search_begin_net(mz_ctx *ctx, int32_t B, const float *obs, const uint8_t 
 int mz_search_run(mz_ctx *ctx, int32_t net_kind, const void *net_params_h, const double *noise,
                   int32_t noise_max_calls, void *stream);
 
+/* mz_search_run followed by mz_to_act (mcts/mcts.py:236-252 as one call): the simulations, then the final
+ * action rule with the outputs of mz_to_act.  Where the search kernel can, the rule runs at the end of the
+ * same launch (small batches, where a launch costs as much as the rule); otherwise two launches.  Same
+ * results as the two calls. */
+int mz_search_run_act(mz_ctx *ctx, int32_t net_kind, const void *net_params_h, const double *noise,
+                      int32_t noise_max_calls, double temperature, const double *u, int32_t *out_action,
+                      double *out_probs, double *out_root_value, double *out_q, void *stream);
+
 /* Copies tree b to host arrays (synchronises `stream`).  Nodes not yet expanded read as a fresh
  * tree's (mcts/mcts.py:72-92). */
 int mz_tree_export(mz_ctx *ctx, int32_t b, mz_tree_host *out_h, void *stream);

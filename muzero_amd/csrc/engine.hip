@@ -342,8 +342,10 @@ extern "C" int mz_expand_backup(mz_ctx *c, const float *logits, const double *va
     return launch_status("mz_expand_backup");
 }
 
-extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, const double *noise,
-                             int32_t noise_max_calls, void *stream)
+// mz_search_run, optionally followed by the final action rule (`act->action` non-NULL).  *act_done tells
+// whether the search kernel already ran the rule.
+static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, const double *noise,
+                      int32_t noise_max_calls, void *stream, const ActOut *act, bool *act_done)
 {
     int rc = check_ctx(c, "mz_search_run");
     if (rc) return rc;
@@ -421,8 +423,10 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
             attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
             if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
+            ActOut ao{};
+            if (act && (size_t)c->net_scratch * 4 >= (size_t)L.rec) { ao = *act; *act_done = true; }
             hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(n_threads), lds_reg, (hipStream_t)stream, c->d, c->net,
-                               c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch, hid_bytes);
+                               c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch, hid_bytes, ao);
             c->n_expanded += n_sims;
             return launch_status("mz_search_run");
         }
@@ -452,6 +456,25 @@ extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params
     MZ_LAUNCH(c, k_search_hash, false, c->B, 0, stream, c->d, hn, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
     c->n_expanded += n_sims;
     return launch_status("mz_search_run");
+}
+
+extern "C" int mz_search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, const double *noise,
+                             int32_t noise_max_calls, void *stream)
+{
+    bool act_done = false;
+    return search_run(c, net_kind, net_params_h, noise, noise_max_calls, stream, nullptr, &act_done);
+}
+
+extern "C" int mz_search_run_act(mz_ctx *c, int32_t net_kind, const void *net_params_h, const double *noise,
+                                 int32_t noise_max_calls, double temperature, const double *u, int32_t *out_action,
+                                 double *out_probs, double *out_root_value, double *out_q, void *stream)
+{
+    if (!out_action || !out_probs || !out_root_value) return fail(MZ_ERR_ARG, "mz_search_run_act: null output");
+    const ActOut act{temperature, u, out_action, out_probs, out_root_value, out_q};
+    bool act_done = false;
+    int rc = search_run(c, net_kind, net_params_h, noise, noise_max_calls, stream, &act, &act_done);
+    if (rc || act_done) return rc;
+    return mz_to_act(c, temperature, u, out_action, out_probs, out_root_value, out_q, stream);
 }
 
 extern "C" int mz_to_act(mz_ctx *c, double temperature, const double *u, int32_t *out_action,

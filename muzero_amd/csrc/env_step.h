@@ -79,7 +79,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, double te
     const int A = d.L.A, OS = e.obs_size;
     bool on = a < A;
     double prob, qout, rv;
-    int action = to_act_rule<RL, GUMBEL>(d, t, a, on, temperature, u ? u[t] : 0.0, &prob, &qout, &rv);
+    int action = to_act_rule<RL, GUMBEL>(d, tree_mem(d, t), t, a, on, temperature, u ? u[t] : 0.0, &prob, &qout, &rv);
     if (on) out_probs[(long long)t * A + a] = prob;
     if (a != 0) return;
     out_action[t] = action;

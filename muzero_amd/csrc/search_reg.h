@@ -38,10 +38,18 @@ __device__ __forceinline__ double lane_read(double v, int lane)  // lane: wave-u
 // lane 24 + k, reward logit i on lane 32 + i, policy logit a on lane 56 + a.
 #define MZ_TINY_HID 24
 #define MZ_TINY_POL 56
+// The final action rule (k_to_act) can run at the end of the same launch: `act.action` non-NULL.
+struct ActOut {
+    double temperature;
+    const double *u;       // [B] uniforms of the final sampling, or NULL
+    int32_t *action;       // [B], NULL: no final rule here
+    double *probs, *root_value, *q;  // [B][A], [B], [B][A] (q may be NULL)
+};
+
 template <int HT>
 __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int first_leaf, int n_sims,
                                                           const double *noise, int noise_max_calls,
-                                                          int scratch_floats, int hid_bytes)
+                                                          int scratch_floats, int hid_bytes, ActOut act)
 {
     extern __shared__ __align__(16) float lds[];
     float *w = lds;
@@ -375,6 +383,31 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         }
     } else {
         for (int i = lane; i < live * H; i += 64) hid_global[i] = hid[i];
+    }
+    if (act.action) {
+        // the root as a record in LDS (the activation scratch is free now); every pair of lanes then evaluates
+        // k_to_act's 2-lane rule on it, lanes 0 and 1 store
+        lds_fence();
+        const TreeMem ml{reinterpret_cast<char *>(sc), nullptr, nullptr};
+        if (lane == 0) {
+            const RowView rv = view(d, ml, 0);
+            NodeHdr h;
+            h.visits = nv; h.parent = par; h.afp = afp; h.to_play = tp; h.value = nval; h.raw = raw;
+            *rv.hdr = h;
+            rv.cvis.set(0, cv0); rv.cvis.set(1, cv1); rv.cidx.set(0, ci0); rv.cidx.set(1, ci1);
+            double *pp = reinterpret_cast<double *>(rv.prior);
+            pp[0] = pr0; pp[1] = pr1; rv.crew[0] = r0; rv.crew[1] = r1; rv.cval[0] = v0; rv.cval[1] = v1;
+        }
+        lds_fence();
+        const bool on = lane < 2;
+        double prob, qout, rvalue;
+        const int chosen = to_act_rule<2, false>(d, ml, t, lane & 1, true, act.temperature, act.u ? act.u[t] : 0.0,
+                                                 &prob, &qout, &rvalue);
+        if (on) {
+            act.probs[(long long)t * 2 + lane] = prob;
+            if (act.q) act.q[(long long)t * 2 + lane] = qout;
+        }
+        if (lane == 0) { act.action[t] = chosen; act.root_value[t] = rvalue; }
     }
 #ifdef MZ_STAMPS
     if (lane == 0) {

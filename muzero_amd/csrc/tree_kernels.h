@@ -242,12 +242,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int
 // mcts/action_selection.py:52-70 (PUCT) / :121-138 (Gumbel) + mcts/tree.py:60-68: the action to play,
 // this lane's policy entry and q entry, and the root value returned by MCTS.search (mcts/mcts.py:252).
 template <int RL, bool GUMBEL>
-__device__ __forceinline__ int to_act_rule(const Dev &d, int t, int a, bool on, double temperature, double uu,
-                                           double *prob_out, double *q_out, double *root_value_out)
+__device__ __forceinline__ int to_act_rule(const Dev &d, const TreeMem &m, int t, int a, bool on, double temperature,
+                                           double uu, double *prob_out, double *q_out, double *root_value_out)
 {
     const int A = d.L.A;
     const double inf = __builtin_huge_val();
-    NodeStats s = load_node<GUMBEL>(d, tree_mem(d, t), 0, a, on);
+    NodeStats s = load_node<GUMBEL>(d, m, 0, a, on);
     bool legal = (d.legal[t] >> a) & 1ull;
     int action;
     double prob, qout;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_to_act(Dev d, double temperature, 
     const int A = d.L.A;
     bool on = a < A;
     double prob, qout, rv;
-    int action = to_act_rule<RL, GUMBEL>(d, t, a, on, temperature, u ? u[t] : 0.0, &prob, &qout, &rv);
+    int action = to_act_rule<RL, GUMBEL>(d, tree_mem(d, t), t, a, on, temperature, u ? u[t] : 0.0, &prob, &qout, &rv);
     if (on) {
         out_probs[(long long)t * A + a] = prob;
         if (out_q) out_q[(long long)t * A + a] = qout;

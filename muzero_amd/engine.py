@@ -50,7 +50,7 @@ class MzEnvState(C.Structure):
 ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
@@ -77,6 +77,7 @@ def lib():
         L.mz_expand_backup.argtypes = [vp, vp, vp, vp, vp, vp]
         L.mz_to_act.argtypes = [vp, f64, vp, vp, vp, vp, vp, vp]
         L.mz_search_run.argtypes = [vp, i32, vp, vp, i32, vp]
+        L.mz_search_run_act.argtypes = [vp, i32, vp, vp, i32, C.c_double, vp, vp, vp, vp, vp, vp]
         L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
         L.mz_set_network_mfma.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.c_int64, vp, i32, i32, vp]
@@ -314,6 +315,18 @@ class SearchEngine:
             max_calls = nz.numel() // (self.B * self.A)
         _check(lib().mz_search_run(self._ctx, NET_DENSE, None, _ptr(nz), max_calls, _stream()))
 
+    def search_net_act(self, temperature=0.0, u=None, noise=None):
+        """search_net followed by to_act as one call (one launch where the search kernel can run the final rule
+        itself).  Returns what to_act returns."""
+        nz, max_calls = None, 0
+        if noise is not None:
+            nz = self._dev(noise, torch.float64)
+            max_calls = nz.numel() // (self.B * self.A)
+        action, value, probs, q, uu = self._act_buffers(u)
+        _check(lib().mz_search_run_act(self._ctx, NET_DENSE, None, _ptr(nz), max_calls, float(temperature), _ptr(uu),
+                                       _ptr(action), _ptr(probs), _ptr(value), _ptr(q), _stream()))
+        return action, value, probs, q
+
     def search_mfma(self, noise=None):
         """All simulations in one launch, leaves evaluated on the matrix cores (set_network_mfma)."""
         nz, max_calls = None, 0
@@ -322,7 +335,7 @@ class SearchEngine:
             max_calls = nz.numel() // (self.B * self.A)
         _check(lib().mz_search_run(self._ctx, NET_MFMA, None, _ptr(nz), max_calls, _stream()))
 
-    def to_act(self, temperature=0.0, u=None):
+    def _act_buffers(self, u):
         B = self.B
         uu = None if u is None else self._dev(u, torch.float64).reshape(B)
         if getattr(self, '_act_out', None) is None or self._act_out[0].shape[0] != B:
@@ -330,7 +343,10 @@ class SearchEngine:
                              torch.empty(B, dtype=torch.float64, device=self.device),
                              torch.empty((B, self.A), dtype=torch.float64, device=self.device),
                              torch.empty((B, self.A), dtype=torch.float64, device=self.device))
-        action, value, probs, q = self._act_out
+        return (*self._act_out, uu)
+
+    def to_act(self, temperature=0.0, u=None):
+        action, value, probs, q, uu = self._act_buffers(u)
         _check(lib().mz_to_act(self._ctx, float(temperature), _ptr(uu), _ptr(action), _ptr(probs), _ptr(value),
                                _ptr(q), _stream()))
         return action, value, probs, q

@@ -276,3 +276,35 @@ def test_networks_near_the_lds_limit_fit_or_fail_cleanly(lanes):
         assert (np.abs(rv.cpu().numpy() - ref.root_value) < 1e-5).mean() >= 0.95
         eng.close()
     assert ran >= 1 and rejected >= 1, (ran, rejected)
+
+
+@pytest.mark.parametrize('B,temperature', [(70, 1.0), (70, 0.0), (2000, 0.5)])
+def test_search_and_final_rule_in_one_call(B, temperature):
+    """mz_search_run_act = mz_search_run + mz_to_act: identical outputs whether the search kernel runs the final
+    rule itself (small batches of 2-action PUCT trees) or the rule is a second launch (large batch)."""
+    from muzero_amd.engine import SearchEngine
+    z, net = load_net('mlp_cartpole')
+    packed = pack_network(net)
+    A, S = 2, 30
+    rng = np.random.default_rng(B)
+    cfg = make_config(False, A, S, 1, 0.997)
+    obs, logits, hidden, value = _roots(net, B, (1, 1, 4), rng)
+    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    legal[5::9, 1] = 0
+    di = rng.dirichlet([0.25] * A, size=B)
+    u = rng.random(B)
+    outs = []
+    for fused in (False, True):
+        eng = SearchEngine(cfg, packed.H, B, seed=21)
+        eng.set_network(packed)
+        prior = eng.root_prepare(logits, legal, di, 0.25)
+        eng.reset(prior, value, hidden, tp, legal)
+        if fused:
+            res = eng.search_net_act(temperature, u)
+        else:
+            eng.search_net()
+            res = eng.to_act(temperature, u)
+        outs.append([x.cpu().numpy().copy() for x in res])
+        eng.close()
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
