@@ -172,6 +172,7 @@ def main():
     # that kernel also runs the final action rule, so search + rule are one launch
     reg_tree = (leaf == 'mlp' and not gumbel and A == 2 and S + 1 <= 64 and B <= 1024 and
                 os.environ.get('MZ_TREE_REG', '1') != '0')
+    one_call = os.environ.get('MZ_BENCH_CALLS', 'act')   # 'move' | 'act' | 'separate': how many launches make a step
 
     def step(i=None):
         if leaf == 'dropin':
@@ -190,6 +191,21 @@ def main():
             if world > 1:  # trajectories of this move to the replay rank
                 mzdist.gather_root_stats(out['action'], out['value'], out['probs'])
             return out
+        if leaf == 'mlp' and reg_tree and one_call == 'move':   # roots, simulations, final action rule: one call
+            if i is not None:
+                ev[i][0].record()
+            out = eng.search_move(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0, temperature, u)
+            if i is not None:
+                ev[i][1].record()
+            return out
+        if leaf == 'mlp' and reg_tree and one_call == 'act':    # roots; simulations + final action rule
+            eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
+            if i is not None:
+                ev[i][0].record()
+            out = eng.search_net_act(temperature, u)
+            if i is not None:
+                ev[i][1].record()
+            return out
         if leaf == 'mlp':
             eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
         elif leaf in ('step', 'mfma', 'mfma_step', 'step5'):
@@ -201,11 +217,6 @@ def main():
             eng.reset(prior, root_value, root_hidden, to_play, legal, gnoise, tree_id0=tree_id0)
         if i is not None:
             ev[i][0].record()
-        if leaf == 'mlp' and reg_tree:   # search + final action rule in one launch
-            out = eng.search_net_act(temperature, u)
-            if i is not None:
-                ev[i][1].record()
-            return out
         if leaf == 'mlp':
             eng.search_net()
         elif leaf == 'mfma':

@@ -184,6 +184,15 @@ int mz_search_run_act(mz_ctx *ctx, int32_t net_kind, const void *net_params_h, c
                       int32_t noise_max_calls, double temperature, const double *u, int32_t *out_action,
                       double *out_probs, double *out_root_value, double *out_q, void *stream);
 
+/* One whole move of B searches as one call: mz_search_begin_net (roots from observations), mz_search_run with
+ * MZ_NET_DENSE, mz_to_act - what MCTS.search (mcts/mcts.py:166-252) does for one position, for B positions.
+ * Arguments as in those three calls.  Small batches of 2-action PUCT trees take two launches (roots; simulations
+ * with the final rule), every other shape three.  Same results as the three calls. */
+int mz_search_move(mz_ctx *ctx, int32_t B, const float *obs, const uint8_t *legal, const int32_t *to_play,
+                   const double *dirichlet, double exploration_frac, const double *gumbel, uint64_t tree_id0,
+                   const double *noise, int32_t noise_max_calls, double temperature, const double *u,
+                   int32_t *out_action, double *out_probs, double *out_root_value, double *out_q, void *stream);
+
 /* Copies tree b to host arrays (synchronises `stream`).  Nodes not yet expanded read as a fresh
  * tree's (mcts/mcts.py:72-92). */
 int mz_tree_export(mz_ctx *ctx, int32_t b, mz_tree_host *out_h, void *stream);

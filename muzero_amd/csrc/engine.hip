@@ -477,6 +477,31 @@ extern "C" int mz_search_run_act(mz_ctx *c, int32_t net_kind, const void *net_pa
     return mz_to_act(c, temperature, u, out_action, out_probs, out_root_value, out_q, stream);
 }
 
+extern "C" int mz_search_move(mz_ctx *c, int32_t B, const float *obs, const uint8_t *legal, const int32_t *to_play,
+                              const double *dirichlet, double frac, const double *gumbel, uint64_t tree_id0,
+                              const double *noise, int32_t noise_max_calls, double temperature, const double *u,
+                              int32_t *out_action, double *out_probs, double *out_root_value, double *out_q,
+                              void *stream)
+{
+    int rc = check_ctx(c, "mz_search_move");
+    if (rc) return rc;
+    if (!c->root.rep_meta) return fail(MZ_ERR_STATE, "mz_search_move: no root network (call mz_set_root_network first)");
+    if (!c->net.meta) return fail(MZ_ERR_STATE, "mz_search_move: no network uploaded (call mz_set_network first)");
+    if (B < 1 || B > c->cfg.max_batch) return fail(MZ_ERR_ARG, "mz_search_move: B outside 1..max_batch");
+    if (!obs || !legal || !to_play) return fail(MZ_ERR_ARG, "mz_search_move: null argument");
+    if (c->cfg.gumbel ? !gumbel : !dirichlet) return fail(MZ_ERR_ARG, "mz_search_move: root noise missing");
+    if (!out_action || !out_probs || !out_root_value) return fail(MZ_ERR_ARG, "mz_search_move: null output");
+    // The roots stay a launch of their own: evaluated by the search kernel's single wave per tree they took longer
+    // than k_begin_net's launch costs, and their arguments crowded the simulation loop's scalar registers.
+    rc = mz_search_begin_net(c, B, obs, legal, to_play, dirichlet, frac, gumbel, tree_id0, nullptr, nullptr, stream);
+    if (rc) return rc;
+    const ActOut act{temperature, u, out_action, out_probs, out_root_value, out_q};
+    bool act_done = false;
+    rc = search_run(c, MZ_NET_DENSE, nullptr, noise, noise_max_calls, stream, &act, &act_done);
+    if (rc || act_done) return rc;
+    return mz_to_act(c, temperature, u, out_action, out_probs, out_root_value, out_q, stream);
+}
+
 extern "C" int mz_to_act(mz_ctx *c, double temperature, const double *u, int32_t *out_action,
                          double *out_probs, double *out_root_value, double *out_q, void *stream)
 {

@@ -15,6 +15,35 @@ struct RootNetDev {
     int obs_off, raw_off, hid_off, pol_off, val_off, obs_size, support, ngroups;
 };
 
+// The root of tree t by its lane group: programs `rw/rm` (representation) and `pw/pm` (prediction) staged in
+// LDS by the block, `sr`/`sp` this group's activation scratch for the two.
+template <int LANES, int RL, bool GUMBEL>
+__device__ __forceinline__ void begin_group(const Dev &d, const RootNetDev &rn, const float *rw, const int32_t *rm,
+                                            const float *pw, const int32_t *pm, float *sr, float *sp, int t, int a,
+                                            const float *obs, const uint8_t *legal, const int32_t *to_play,
+                                            const double *dirichlet, double frac, const double *gumbel,
+                                            int max_considered, float *out_logits, double *out_value)
+{
+    const int A = d.L.A, H = d.L.H;
+    bool on = a < A;
+    for (int i = a; i < rn.obs_size; i += LANES) sr[rn.obs_off + i] = obs[(long long)t * rn.obs_size + i];
+    lds_fence();
+    dense_run<LANES>(rm, rw, sr, a);
+    minmax_to<LANES>(sr + rn.raw_off, H, rn.ngroups, a, d.hidden + (long long)t * d.L.N * H, sp + rn.hid_off);
+    lds_fence();
+    dense_run<LANES>(pm, pw, sp, a);
+    double value = support_to_scalar<LANES>(sp + rn.val_off, rn.support, a);
+    float lg = on ? sp[rn.pol_off + a] : 0.0f;
+    long long k = (long long)t * A + a;
+    bool lgl = on && legal[k] != 0;
+    double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
+    double pr = root_prior<RL, GUMBEL>(lg, on, lgl, di, frac, a, A, true);
+    write_root<LANES, GUMBEL>(d, t, a, on, pr, value, to_play[t], lgl, (GUMBEL && on) ? gumbel[k] : 0.0,
+                              max_considered);
+    if (out_logits && on) out_logits[k] = lg;
+    if (out_value && a == 0) out_value[t] = value;
+}
+
 template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_begin_net(Dev d, RootNetDev rn, const float *obs,
                                                          const uint8_t *legal, const int32_t *to_play,
@@ -38,24 +67,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_begin_net(Dev d, RootNetDev rn, co
     __syncthreads();
     int t, a;
     if (!group_ids<LANES>(d, &t, &a)) return;
-    const int A = d.L.A, H = d.L.H;
-    bool on = a < A;
-    for (int i = a; i < rn.obs_size; i += LANES) sr[rn.obs_off + i] = obs[(long long)t * rn.obs_size + i];
-    lds_fence();
-    dense_run<LANES>(rm, rw, sr, a);
-    minmax_to<LANES>(sr + rn.raw_off, H, rn.ngroups, a, d.hidden + (long long)t * d.L.N * H, sp + rn.hid_off);
-    lds_fence();
-    dense_run<LANES>(pm, pw, sp, a);
-    double value = support_to_scalar<LANES>(sp + rn.val_off, rn.support, a);
-    float lg = on ? sp[rn.pol_off + a] : 0.0f;
-    long long k = (long long)t * A + a;
-    bool lgl = on && legal[k] != 0;
-    double di = (!GUMBEL && on) ? dirichlet[k] : 0.0;
-    double pr = root_prior<RL, GUMBEL>(lg, on, lgl, di, frac, a, A, true);
-    write_root<LANES, GUMBEL>(d, t, a, on, pr, value, to_play[t], lgl, (GUMBEL && on) ? gumbel[k] : 0.0,
-                              max_considered);
-    if (out_logits && on) out_logits[k] = lg;
-    if (out_value && a == 0) out_value[t] = value;
+    begin_group<LANES, RL, GUMBEL>(d, rn, rw, rm, pw, pm, sr, sp, t, a, obs, legal, to_play, dirichlet, frac, gumbel,
+                                   max_considered, out_logits, out_value);
 }
 
 // TREE_LDS: each group's node records, hidden states and path live in LDS for the whole search (staged in

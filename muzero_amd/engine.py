@@ -50,7 +50,7 @@ class MzEnvState(C.Structure):
 ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
@@ -77,6 +77,7 @@ def lib():
         L.mz_expand_backup.argtypes = [vp, vp, vp, vp, vp, vp]
         L.mz_to_act.argtypes = [vp, f64, vp, vp, vp, vp, vp, vp]
         L.mz_search_run.argtypes = [vp, i32, vp, vp, i32, vp]
+        L.mz_search_move.argtypes = [vp, i32, vp, vp, vp, vp, C.c_double, vp, C.c_uint64, vp, i32, C.c_double, vp, vp, vp, vp, vp, vp]
         L.mz_search_run_act.argtypes = [vp, i32, vp, vp, i32, C.c_double, vp, vp, vp, vp, vp, vp]
         L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
@@ -314,6 +315,33 @@ class SearchEngine:
             nz = self._dev(noise, torch.float64)
             max_calls = nz.numel() // (self.B * self.A)
         _check(lib().mz_search_run(self._ctx, NET_DENSE, None, _ptr(nz), max_calls, _stream()))
+
+    def search_move(self, obs, legal, to_play, dirichlet=None, exploration_frac=0.0, gumbel=None, tree_id0=0,
+                    temperature=0.0, u=None, noise=None):
+        """begin_net + search_net + to_act as one call (two launches for small batches of 2-action PUCT trees,
+        else three).  Returns what to_act returns."""
+        ob = self._dev(obs, torch.float32)
+        B = ob.shape[0]
+        ob = ob.reshape(B, self.obs_size)
+        le = legal if (torch.is_tensor(legal) and legal.dtype == torch.uint8 and legal.device == self.device) else \
+            self._dev(np.asarray(legal) != 0 if not torch.is_tensor(legal) else legal != 0, torch.uint8, (B, self.A))
+        tp = self._dev(to_play, torch.int32).reshape(B)
+        di = None if dirichlet is None else self._dev(dirichlet, torch.float64, (B, self.A))
+        gu = None if gumbel is None else self._dev(gumbel, torch.float64, (B, self.A))
+        self.B = B
+        nz, max_calls = None, 0
+        if noise is not None:
+            nz = self._dev(noise, torch.float64)
+            max_calls = nz.numel() // (B * self.A)
+        action, value, probs, q, uu = self._act_buffers(u)
+        _check(lib().mz_search_move(self._ctx, B, _ptr(ob), _ptr(le), _ptr(tp), _ptr(di), float(exploration_frac), _ptr(gu),
+                                    C.c_uint64(int(tree_id0)), _ptr(nz), max_calls, float(temperature), _ptr(uu),
+                                    _ptr(action), _ptr(probs), _ptr(value), _ptr(q), _stream()))
+        if self._parent is None or self._parent.shape[0] != B:
+            self._parent = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._action = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._phid = torch.empty((B, self.H), dtype=torch.float32, device=self.device) if self.H else None
+        return action, value, probs, q
 
     def search_net_act(self, temperature=0.0, u=None, noise=None):
         """search_net followed by to_act as one call (one launch where the search kernel can run the final rule

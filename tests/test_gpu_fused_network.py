@@ -308,3 +308,40 @@ def test_search_and_final_rule_in_one_call(B, temperature):
         eng.close()
     for x, y in zip(*outs):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize('B,gumbel', [(70, False), (1, False), (2000, False), (70, True)])
+def test_whole_move_in_one_call(B, gumbel):
+    """mz_search_move = mz_search_begin_net + mz_search_run + mz_to_act: identical outputs and trees whether
+    the move is a single launch (small batches of 2-action PUCT trees) or three."""
+    from muzero_amd.engine import SearchEngine
+    z, net = load_net('mlp_cartpole')
+    packed = pack_network(net)
+    A, S = 2, 30
+    rng = np.random.default_rng(B + gumbel)
+    cfg = make_config(gumbel, A, S, 1, 0.997)
+    obs = rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32)
+    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    legal[5::9, 1] = 0
+    di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
+    g = rng.gumbel(size=(B, A)) if gumbel else None
+    u = rng.random(B)
+    outs = []
+    for fused in (False, True):
+        eng = SearchEngine(cfg, packed.H, B, seed=21)
+        eng.set_network(packed)
+        if fused:
+            res = eng.search_move(obs, legal, tp, di, 0.25, g, 7, 1.0, u)
+        else:
+            eng.begin_net(obs, legal, tp, di, 0.25, g, tree_id0=7)
+            eng.search_net()
+            res = eng.to_act(1.0, u)
+        nv, calls = eng.stats()
+        trees = [eng.export_tree(b) for b in range(0, B, max(1, B // 5))]
+        outs.append(([x.cpu().numpy().copy() for x in res] + [nv.cpu().numpy().copy(), calls.cpu().numpy().copy()], trees))
+        eng.close()
+    for x, y in zip(outs[0][0], outs[1][0]):
+        np.testing.assert_array_equal(x, y)
+    for t0, t1 in zip(outs[0][1], outs[1][1]):
+        for k in t0:
+            np.testing.assert_array_equal(t0[k], t1[k], err_msg=k)
