@@ -279,8 +279,8 @@ def main():
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
                      'limiter': 'not HBM: the shader-sequencer counters (profiles/round1_final_sq_counters.txt) show the '
-                                'large-batch tree kernels at ~80% of the VALU issue rate and the 256-tree search waiting on '
-                                'dependent-instruction and LDS latency of one wave per tree'},
+                                'large-batch tree kernels at ~80% of the VALU issue rate; the 256-tree search is one wave per '
+                                'tree with the tree in registers, ~1000 dependent instructions per simulation at ~4.7 cycles each'},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

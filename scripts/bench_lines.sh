@@ -1,0 +1,12 @@
+#!/bin/bash
+# GPU box: one bench line per workload (the default one with its CPU baseline) into gpurun_out/<tag>_bench_lines.jsonl
+set -e
+tag=${1:-lines}
+out=gpurun_out/${tag}_bench_lines.jsonl
+: > $out
+timeout -k 10 300 python bench.py --workload cfg1 --steps 50 --warmup 5 --no-cpu-baseline 2> gpurun_out/${tag}_cfg1.err | tail -1 >> $out
+timeout -k 10 300 python bench.py 2> gpurun_out/${tag}_cfg2.err | tail -1 >> $out
+for w in cfg4s cfg4 cfg3 cfg3h cfg5 cfg5h; do
+    timeout -k 10 300 python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline 2> gpurun_out/${tag}_$w.err | tail -1 >> $out
+    echo "done $w"
+done
