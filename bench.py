@@ -168,9 +168,9 @@ def main():
     temperature = 1.0
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    # small batches of 2-action PUCT trees (<= 64 nodes) run with the tree in registers (csrc/search_reg.h);
+    # 2-action PUCT trees (<= 64 nodes) run with the tree in registers (csrc/search_reg.h);
     # that kernel also runs the final action rule, so search + rule are one launch
-    reg_tree = (leaf == 'mlp' and not gumbel and A == 2 and S + 1 <= 64 and B <= 1024 and
+    reg_tree = (leaf == 'mlp' and not gumbel and A == 2 and S + 1 <= 64 and
                 os.environ.get('MZ_TREE_REG', '1') != '0')
     one_call = os.environ.get('MZ_BENCH_CALLS', 'act')   # 'move' | 'act' | 'separate': how many launches make a step
 
@@ -275,7 +275,7 @@ def main():
         'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
                                 'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
-                                'selfplay': 'k_begin_net+k_search_net+k_act_env'}[leaf],
+                                'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
                      'limiter': 'not HBM: the shader-sequencer counters (profiles/round1_final_sq_counters.txt) show the '

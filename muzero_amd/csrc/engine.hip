@@ -410,12 +410,17 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
         bool tree_in_lds = c->lanes == 64 && n_blocks <= 256 && lds_tree + lds_static <= 160 * 1024;
         if (const char *e = getenv("MZ_TREE_LDS")) tree_in_lds = tree_in_lds && atoi(e) != 0;
         hipError_t attr_err = hipSuccess;
-        // 2-action PUCT trees of at most 64 nodes served by whole waves: the tree lives in registers
+        // 2-action PUCT trees of at most 64 nodes: one wave per tree with the tree in registers, whatever group
+        // width the context was created with (measured faster than the lane groups at 256 and at 8192 trees)
         bool tiny = c->net_tiny;
         if (const char *e = getenv("MZ_NET_TINY")) tiny = tiny && atoi(e) != 0;
         const int hid_bytes = tiny ? 0 : (L.N * L.H * 4 + 15) & ~15;
-        const size_t lds_reg = ((lds + 15) & ~(size_t)15) + (size_t)gpb * hid_bytes;
-        bool tree_in_regs = c->lanes == 64 && !c->cfg.gumbel && L.A == 2 && L.N <= 64 && c->net_small && !L.prior_f32 &&
+        int wpb = MZ_BLOCK / 64;  // waves (= trees) per block: fewer for small batches, so that they spread over all CUs
+        while (wpb > 1 && (c->B + wpb - 1) / wpb < 256) wpb >>= 1;
+        auto lds_reg_for = [&](int g) { return ((lds_for(g) + 15) & ~(size_t)15) + (size_t)g * hid_bytes; };
+        while (wpb > 1 && lds_reg_for(wpb) + (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8 > 160 * 1024) wpb >>= 1;
+        const size_t lds_reg = lds_reg_for(wpb);
+        bool tree_in_regs = !c->cfg.gumbel && L.A == 2 && L.N <= 64 && c->net_small && !L.prior_f32 &&
                             lds_reg + (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8 <= 160 * 1024;
         if (const char *e = getenv("MZ_TREE_REG")) tree_in_regs = tree_in_regs && atoi(e) != 0;
         if (tree_in_regs) {
@@ -425,8 +430,9 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
             if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
             ActOut ao{};
             if (act && (size_t)c->net_scratch * 4 >= (size_t)L.rec) { ao = *act; *act_done = true; }
-            hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(n_threads), lds_reg, (hipStream_t)stream, c->d, c->net,
-                               c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch, hid_bytes, ao);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((c->B + wpb - 1) / wpb)), dim3((unsigned)(wpb * 64)), lds_reg,
+                               (hipStream_t)stream, c->d, c->net, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls,
+                               c->net_scratch, hid_bytes, ao);
             c->n_expanded += n_sims;
             return launch_status("mz_search_run");
         }

@@ -23,7 +23,7 @@ def _roots(net, B, obs_shape, rng):
 
 
 @pytest.mark.parametrize('gumbel', [False, True])
-def test_fused_mlp_search_vs_checker(gumbel):
+def test_fused_mlp_search_vs_checker(gumbel, monkeypatch):
     from muzero_amd.engine import SearchEngine
     from oracle import oracle as orc
     z, net = load_net('mlp_cartpole')
@@ -38,7 +38,8 @@ def test_fused_mlp_search_vs_checker(gumbel):
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     ref = orc.search_batch_net(cfg, packed, logits, hidden, value, legal, tp, dirichlet=di, frac=0.25, gumbel=g,
                                seed=5, tree_id0=0, n_threads=8)
-    for lanes in (2, 16, 64):
+    for lanes, reg in ((2, '0'), (16, '0'), (64, '0'), (64, '1')):   # lane groups of every width, then trees in registers
+        monkeypatch.setenv('MZ_TREE_REG', reg)
         eng = SearchEngine(cfg, packed.H, B, seed=5, lanes_per_tree=lanes)
         eng.set_network(packed)
         prior = eng.root_prepare(logits, legal, di, 0.25)
