@@ -350,10 +350,9 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         if (lane == parent) {
             if (action) { ci1 = leaf; r1 = reward; } else { ci0 = leaf; r0 = reward; }
         }
-        if (lane == leaf) {
+        if (lane == leaf) {  // the lane still holds a fresh node's child rows (no visits, no links, zero rewards and values)
             nv = 1; par = parent; afp = action; tp = ntp; nval = value; raw = value; dep = depth;
-            cv0 = 0; cv1 = 0; ci0 = -1; ci1 = -1;
-            pr0 = (double)lg0; pr1 = (double)lg1; r0 = 0.0; r1 = 0.0; v0 = 0.0; v1 = 0.0;
+            pr0 = (double)lg0; pr1 = (double)lg1;
         }
         maxdep = depth > maxdep ? depth : maxdep;
         lds_fence();
