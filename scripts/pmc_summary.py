@@ -4,7 +4,7 @@ dominant kernel.  Usage: python scripts/pmc_summary.py <tag> <round-name>"""
 import csv, glob, json, os, shutil, sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
-DOMINANT = {'cfg2': 'k_search_reg', 'cfg4s': 'k_search_net', 'cfg3h': 'k_search_hash'}
+DOMINANT = {'cfg2': 'k_search_reg', 'cfg4s': 'k_search_reg', 'cfg3h': 'k_search_hash'}
 NOTE = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py (5 steps), mean over the '
         'kernel launches; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (counters are in KiB; gfx950 tallies 128-byte '
         'read requests at 64 bytes).  Calibrated on this access pattern with k_to_act of the same runs: 8192 root '
