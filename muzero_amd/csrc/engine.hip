@@ -414,7 +414,10 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
         // width the context was created with (measured faster than the lane groups at 256 and at 8192 trees)
         bool tiny = c->net_tiny;
         if (const char *e = getenv("MZ_NET_TINY")) tiny = tiny && atoi(e) != 0;
-        const int hid_bytes = tiny ? 0 : (L.N * L.H * 4 + 15) & ~15;
+        // hidden states of the smallest networks: registers while a wave has its SIMD to itself, LDS when the chip is full
+        bool hid_lds = tiny && c->B > 1024;
+        if (const char *e = getenv("MZ_HID_LDS")) hid_lds = tiny && atoi(e) != 0;
+        const int hid_bytes = (tiny && !hid_lds) ? 0 : (L.N * L.H * 4 + 15) & ~15;
         int wpb = MZ_BLOCK / 64;  // waves (= trees) per block: fewer for small batches, so that they spread over all CUs
         while (wpb > 1 && (c->B + wpb - 1) / wpb < 256) wpb >>= 1;
         auto lds_reg_for = [&](int g) { return ((lds_for(g) + 15) & ~(size_t)15) + (size_t)g * hid_bytes; };
@@ -424,7 +427,8 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
                             lds_reg + (size_t)(MZ_CT_LDS + MZ_SQ_LDS) * 8 <= 160 * 1024;
         if (const char *e = getenv("MZ_TREE_REG")) tree_in_regs = tree_in_regs && atoi(e) != 0;
         if (tree_in_regs) {
-            auto kern = !tiny ? k_search_reg<0> : L.H == 8 ? k_search_reg<8> : k_search_reg<4>;
+            auto kern = !tiny ? k_search_reg<0> : L.H == 8 ? (hid_lds ? k_search_reg<8, true> : k_search_reg<8>)
+                                                            : (hid_lds ? k_search_reg<4, true> : k_search_reg<4>);
             attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
             if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");

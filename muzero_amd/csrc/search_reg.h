@@ -46,7 +46,10 @@ struct ActOut {
     double *probs, *root_value, *q;  // [B][A], [B], [B][A] (q may be NULL)
 };
 
-template <int HT>
+// HLDS (TINY only): hidden states in LDS instead of registers - one broadcast read feeds the first level and one
+// store keeps the new state, 22 vector instructions fewer per simulation for two more LDS round trips: the better
+// trade when the chip is full and instruction issue is the bound, the worse one for a lone wave per SIMD.
+template <int HT, bool HLDS = false>
 __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int first_leaf, int n_sims,
                                                           const double *noise, int noise_max_calls,
                                                           int scratch_floats, int hid_bytes, ActOut act)
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
     float hreg[HR];  // TINY: this lane's node's hidden state
 #pragma unroll
     for (int k = 0; k < HR; k++) hreg[k] = 0.0f;
-    if constexpr (TINY) {
+    if constexpr (TINY && !HLDS) {
         if (lane < first_leaf) {
 #pragma unroll
             for (int k = 0; k < HT; k++) hreg[k] = hid_global[lane * HT + k];
@@ -233,8 +236,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
             float x[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                if (k < HT) x[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[k < HT ? k : 0]), parent));
-                else x[k] = (k - HT < 2 && k - HT == action) ? 1.0f : 0.0f;
+                if (k < HT) {
+                    if constexpr (HLDS) x[k] = hid[parent * HT + k];  // same address on every lane: a broadcast read
+                    else x[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[k < HT ? k : 0]), parent));
+                } else {
+                    x[k] = (k - HT < 2 && k - HT == action) ? 1.0f : 0.0f;
+                }
             }
 #ifdef MZ_STAMPS
             MZ_STAMP(st_in)
@@ -301,10 +308,14 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
             const double y = inv_value_transform(xs);
             value = wave_lane(y, 0);
             reward = wave_lane(y, 32);
+            if constexpr (HLDS) {
+                if (has_h) hid[leaf * HT + lane - MZ_TINY_HID] = hv;
+            } else {
 #pragma unroll
-            for (int k = 0; k < HT; k++) {
-                const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), MZ_TINY_HID + k));
-                hreg[k] = lane == leaf ? hk : hreg[k];
+                for (int k = 0; k < HT; k++) {
+                    const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), MZ_TINY_HID + k));
+                    hreg[k] = lane == leaf ? hk : hreg[k];
+                }
             }
             lg0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out2), MZ_TINY_POL));
             lg1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out2), MZ_TINY_POL + 1));
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         double *pp = reinterpret_cast<double *>(rv.prior);
         pp[0] = pr0; pp[1] = pr1; rv.crew[0] = r0; rv.crew[1] = r1; rv.cval[0] = v0; rv.cval[1] = v1;
     }
-    if constexpr (TINY) {
+    if constexpr (TINY && !HLDS) {
         if (lane < live) {
 #pragma unroll
             for (int k = 0; k < HT; k++) hid_global[lane * HT + k] = hreg[k];

@@ -114,10 +114,13 @@ def test_lds_resident_tree_is_bit_identical(gumbel, deep, monkeypatch):
     for stepped in (0, 7):
         out = []
         # trees in global memory, in LDS, in registers (hidden states in LDS), in registers with hidden states too
-        for flag, reg, tiny in (('0', '0', '0'), ('1', '0', '0'), ('1', '1', '0'), ('1', '1', '1')):
+        # ... and the same with those hidden states in LDS again (what batches that fill the chip use)
+        for flag, reg, tiny, hlds in (('0', '0', '0', '0'), ('1', '0', '0', '0'), ('1', '1', '0', '0'), ('1', '1', '1', '0'),
+                                      ('1', '1', '1', '1')):
             monkeypatch.setenv('MZ_TREE_LDS', flag)
             monkeypatch.setenv('MZ_TREE_REG', reg)
             monkeypatch.setenv('MZ_NET_TINY', tiny)
+            monkeypatch.setenv('MZ_HID_LDS', hlds)
             eng = SearchEngine(cfg, packed.H, B, seed=13, lanes_per_tree=64)
             eng.set_network(packed)
             prior = eng.root_prepare(logits, legal, di, 0.25)
