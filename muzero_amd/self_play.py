@@ -51,13 +51,23 @@ class DeviceEnvs:
                                          p(self.state), p(self.mover), p(self.to_play), p(self.legal),
                                          p(self.cur_obs), p(self.search_obs), p(self.moves), p(self.reset_state))
 
+    NOISE_BLOCK = 16   # moves whose random inputs are drawn by one set of launches
+
     def refresh_reset_states(self):
-        """New initial states for environments that restart on the next step (CartPole), drawn on the device."""
+        """New initial states for environments that restart on the next step (CartPole), drawn on the device:
+        NOISE_BLOCK moves' worth per draw, one slice handed to the step kernel per move."""
         if self.reset_state is not None:
             if getattr(self, '_gen', None) is None:
                 self._gen = torch.Generator(device=self.device)
                 self._gen.manual_seed(int(self.rng.integers(0, 2**31)))
-            self.reset_state.uniform_(-0.05, 0.05, generator=self._gen)
+                self._reset_block, self._reset_k = None, self.NOISE_BLOCK
+            if self._reset_k >= self.NOISE_BLOCK:
+                self._reset_block = torch.empty((self.NOISE_BLOCK,) + tuple(self.reset_state.shape), dtype=self.reset_state.dtype,
+                                                device=self.device).uniform_(-0.05, 0.05, generator=self._gen)
+                self._reset_k = 0
+            self.reset_state = self._reset_block[self._reset_k]
+            self.struct.reset_state = self.reset_state.data_ptr()
+            self._reset_k += 1
 
 
 class BatchedSelfPlay:
@@ -105,17 +115,28 @@ class BatchedSelfPlay:
 
     # ------------------------------------------------------------------ one move for every environment
     def _root_noise(self):
-        """Fresh Gumbel / Dirichlet root noise for every environment, drawn on the device."""
-        A, B = self.envs.A, self.B
+        """Fresh Gumbel / Dirichlet root noise (and the final sampling uniforms) for every environment, drawn on
+        the device for DeviceEnvs.NOISE_BLOCK moves at a time: the half dozen small generator launches then cost
+        a sixteenth per move."""
+        A, B, K = self.envs.A, self.B, DeviceEnvs.NOISE_BLOCK
         if getattr(self, '_gen', None) is None:
             self._gen = torch.Generator(device=self.device)
             self._gen.manual_seed(int(self.rng.integers(0, 2**31)))
-        if self.gumbel:
-            uu = torch.rand((B, A), dtype=torch.float64, device=self.device, generator=self._gen).clamp_min_(1e-300)
-            return None, -torch.log(-torch.log(uu))
-        alpha = torch.full((B, A), float(self.config.dirichlet_alpha), dtype=torch.float64, device=self.device)
-        gam = torch._standard_gamma(alpha, generator=self._gen).clamp_min_(1e-300)
-        return gam / gam.sum(dim=1, keepdim=True), None
+            self._noise_k = K
+        if self._noise_k >= K:
+            self._u_block = torch.rand((K, B), dtype=torch.float64, device=self.device, generator=self._gen)
+            if self.gumbel:
+                uu = torch.rand((K, B, A), dtype=torch.float64, device=self.device, generator=self._gen).clamp_min_(1e-300)
+                self._noise_block = -torch.log(-torch.log(uu))
+            else:
+                alpha = torch.full((K, B, A), float(self.config.dirichlet_alpha), dtype=torch.float64, device=self.device)
+                gam = torch._standard_gamma(alpha, generator=self._gen).clamp_min_(1e-300)
+                self._noise_block = gam / gam.sum(dim=2, keepdim=True)
+            self._noise_k = 0
+        k = self._noise_k
+        self._noise_k += 1
+        self._u_next = self._u_block[k]
+        return (None, self._noise_block[k]) if self.gumbel else (self._noise_block[k], None)
 
     def step(self, temperature: float = 1.0, root_noise=None, u=None, noise=None):
         """Searches and plays one move in every environment.  root_noise: (dirichlet, gumbel) tensors
@@ -156,7 +177,9 @@ class BatchedSelfPlay:
                         eng.expand_backup(l2.reshape(self.B, e.A), v2.reshape(self.B), r2.reshape(self.B),
                                           nh.reshape(self.B, -1))
         if u is None and not self.gumbel:
-            u = torch.rand(self.B, dtype=torch.float64, device=self.device, generator=self._gen)
+            if root_noise is not None or getattr(self, '_u_next', None) is None:
+                self._root_noise()   # advances the block that also holds the sampling uniforms
+            u, self._u_next = self._u_next, None
         e.refresh_reset_states()
         eng.act_env_step(e.struct, temperature, u, self.out)
         self.steps_done += 1
