@@ -27,6 +27,7 @@ sys.path.insert(0, REPO)
 
 from muzero_amd import distributed as mzdist  # noqa: E402
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense float32 matrix peak of MI355X (no xf32 on gfx950)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
@@ -101,6 +102,7 @@ def main():
     from muzero_amd import hashnet
 
     desc, gumbel, A, S, players, gamma, B, leaf = WORKLOADS[args.workload]
+    leaf_macs = None
     cfg = search_config(gumbel, A, S, players, gamma)
     rng = np.random.default_rng(1 + rank)
     tree_id0 = rank * B
@@ -139,14 +141,18 @@ def main():
         net = MuZeroNetwork(atari_like_net_config(), seed=0).to(dev)
         H = net.H
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
-        eng.set_network_mfma(*pack_network_mfma(net))
+        pm_io = pack_network_mfma(net)
+        leaf_macs = (pm_io[0].macs, pm_io[0].padded_macs)
+        eng.set_network_mfma(*pm_io)
         obs = torch.as_tensor(rng.standard_normal((B, 128)).astype(np.float32), device=dev)
     elif leaf in ('step', 'mfma'):
         from muzero_amd.packing import pack_network_mfma
         net = MuZeroNetwork(tictactoe_net_config(), seed=0).to(dev)
         H = net.H
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
-        eng.set_network_mfma(*pack_network_mfma(net))
+        pm_io = pack_network_mfma(net)
+        leaf_macs = (pm_io[0].macs, pm_io[0].padded_macs)
+        eng.set_network_mfma(*pm_io)
         boards = rng.integers(0, 3, size=(B, 9)) - 1  # random (not necessarily reachable) positions
         planes = np.stack([(boards == -1), (boards == 1), np.ones_like(boards) * -1], axis=1).astype(np.float32)
         obs = torch.as_tensor(planes.reshape(B, 27), device=dev)
@@ -283,6 +289,15 @@ def main():
                                 'tree with the tree in registers, ~1000 dependent instructions per simulation at ~4.7 cycles each'},
     }
 
+    if leaf in ('mfma', 'mfma_step') and leaf_macs is not None:
+        # leaves evaluated on the matrix cores: the lowered network's multiply-accumulates (unpadded) per leaf x leaves
+        # per launch / the same launch time, against the dense float32 MFMA peak (v_mfma_f32_16x16x4_f32)
+        tf = 2.0 * leaf_macs[0] * B * S / (kern_ms * 1e-3) / 1e12
+        out['roofline_mfma'] = {'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': tf / MFMA_F32_PEAK_TFLOPS, 'flop_per_leaf': 2 * leaf_macs[0],
+                                'executed_flop_per_leaf': 2 * leaf_macs[1],
+                                'note': 'the launch also holds the tree operations of the same simulations; MFMA busy cycles '
+                                        'from the counters: profiles/round1_final_mfma_counters.txt'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, packed, leaf, A, S, H, B, gumbel)
     if rank == 0:
