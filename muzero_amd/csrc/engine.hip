@@ -10,6 +10,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <unordered_map>
 #include "../../include/muzero_amd.h"
 #include "tree_kernels.h"  // device_common.h, tree_ops.h
 #include "dense_net.h"
@@ -258,6 +259,18 @@ static int check_ctx(mz_ctx *c, const char *fn)
     return MZ_OK;
 }
 
+// hipFuncSetAttribute costs microseconds of host time per call: the dynamic LDS limit of a kernel is raised only when
+// a launch needs more than an earlier one was granted (one device per process: the limit is per device and function).
+static hipError_t ensure_dynamic_lds(const void *kern, size_t bytes)
+{
+    static std::unordered_map<const void *, size_t> granted;
+    size_t &g = granted[kern];
+    if (bytes <= g) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) g = bytes;
+    return e;
+}
+
 static int launch_status(const char *fn)
 {
     hipError_t e = hipGetLastError();
@@ -368,8 +381,7 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
             return fail(MZ_ERR_ARG, "mz_search_run: activations of a 32-tree tile do not fit in LDS beside the backup staging; use the step API");
         hipError_t attr_err = hipSuccess;
         auto launch = [&](auto kern) {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+            attr_err = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)lds);
             hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream,
                                c->d, c->mnet, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
         };
@@ -429,8 +441,7 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
         if (tree_in_regs) {
             auto kern = !tiny ? k_search_reg<0> : L.H == 8 ? (hid_lds ? k_search_reg<8, true> : k_search_reg<8>)
                                                             : (hid_lds ? k_search_reg<4, true> : k_search_reg<4>);
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            attr_err = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)lds_reg);
             if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
             ActOut ao{};
             if (act && (size_t)c->net_scratch * 4 >= (size_t)L.rec) { ao = *act; *act_done = true; }
@@ -444,8 +455,7 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
             constexpr int LN = decltype(L_)::value, RN = decltype(R_)::value;
             constexpr bool GM = decltype(G_)::value;
             auto launch = [&](auto kern, size_t bytes, int tree_bytes) {
-                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+                attr_err = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)bytes);
                 hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(n_threads), bytes, (hipStream_t)stream, c->d,
                                    c->net, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls, c->net_scratch,
                                    tree_bytes);
@@ -859,8 +869,7 @@ extern "C" int mz_search_begin_net(mz_ctx *c, int32_t B, const float *obs, const
     hipError_t attr_err = hipSuccess;
     dispatch_shape(c->lanes, c->rl, c->cfg.gumbel != 0, [&](auto L_, auto R_, auto G_) {
         auto kern = k_begin_net<decltype(L_)::value, decltype(R_)::value, decltype(G_)::value>;
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_err = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)lds);
         hipLaunchKernelGGL(kern, dim3(grid_for(B, decltype(L_)::value)), dim3(MZ_BLOCK), lds, (hipStream_t)stream,
                            c->d, r, obs, legal, to_play, dirichlet, frac, gumbel,
                            (int)c->cfg.max_considered_actions, out_logits, out_value);
@@ -968,8 +977,8 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
         const int32_t *jobs = (const int32_t *)c->mnet_bufs[5];
         const unsigned tree_tiles = (unsigned)((c->B + 31) / 32);
         const size_t lds = (size_t)(c->mnet_max_k16 * 16 + 4) * 32 * 4;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_level<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_net_level<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(ensure_dynamic_lds(reinterpret_cast<const void *>(&k_net_level<true>), lds));
+        HIPCHK(ensure_dynamic_lds(reinterpret_cast<const void *>(&k_net_level<false>), lds));
         for (int l = 0; l < c->mnet.n_levels; l++) {
             const int j0 = c->mnet_level_job0[l], nb = c->mnet_level_job0[l + 1] - j0;
             if (nb < 1) continue;
@@ -991,7 +1000,7 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
         size_t lds = (size_t)c->mnet.stride * tm * 4;
         auto kern = tm == 32 ? k_net_step<32> : k_net_step<16>;
         // per launch, like the other kernels with large dynamic LDS: the attribute belongs to the current device
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)lds));
         hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream, c->d,
                            c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
     }

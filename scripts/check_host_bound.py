@@ -25,6 +25,13 @@ def step():
 for _ in range(50): step()
 torch.cuda.synchronize()
 N=2000
+# a short burst first: with few launches in flight the queue never pushes back, so this is the host's own cost
+torch.cuda.synchronize()
+b0=time.perf_counter()
+for _ in range(20): step()
+b1=time.perf_counter()
+torch.cuda.synchronize()
+print('host cost per step (burst of 20) us', (b1-b0)/20*1e6)
 t0=time.perf_counter()
 for _ in range(N): step()
 t1=time.perf_counter()
