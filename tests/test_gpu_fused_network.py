@@ -349,3 +349,40 @@ def test_whole_move_in_one_call(B, gumbel):
     for t0, t1 in zip(outs[0][1], outs[1][1]):
         for k in t0:
             np.testing.assert_array_equal(t0[k], t1[k], err_msg=k)
+
+
+@pytest.mark.parametrize('S,B', [(1, 1), (2, 3), (63, 5), (64, 5)])
+def test_register_tree_edge_shapes(S, B, monkeypatch):
+    """The smallest search, a tree that fills all 64 lanes (63 simulations) and one that no longer fits (64):
+    the register path - or whatever takes over from it - equals the lane-group path bit for bit, also with a
+    root whose actions are all illegal."""
+    from muzero_amd.engine import SearchEngine
+    z, net = load_net('mlp_cartpole')
+    packed = pack_network(net)
+    A = 2
+    rng = np.random.default_rng(S * 10 + B)
+    cfg = make_config(False, A, S, 2, 0.997)
+    obs, logits, hidden, value = _roots(net, B, (1, 1, 4), rng)
+    legal, tp = np.ones((B, A)), rng.integers(0, 2, size=B).astype(np.int32)
+    legal[-1] = 0   # no legal action at the last root
+    di = rng.dirichlet([0.25] * A, size=B)
+    out = []
+    for reg in ('0', '1'):
+        monkeypatch.setenv('MZ_TREE_REG', reg)
+        monkeypatch.setenv('MZ_TREE_LDS', '0')
+        eng = SearchEngine(cfg, packed.H, B, seed=2)
+        eng.set_network(packed)
+        prior = eng.root_prepare(logits, legal, di, 0.25)
+        eng.reset(prior, value, hidden, tp, legal)
+        res = eng.search_net_act(1.0, rng.random(B) * 0 + 0.37)
+        nv, calls = eng.stats()
+        out.append(([x.cpu().numpy().copy() for x in res], [eng.export_tree(b) for b in range(B)], nv.cpu().numpy().copy(),
+                    calls.cpu().numpy().copy()))
+        eng.close()
+    for x, y in zip(out[0][0], out[1][0]):
+        np.testing.assert_array_equal(x, y)
+    for t0, t1 in zip(out[0][1], out[1][1]):
+        for k in t0:
+            np.testing.assert_array_equal(t0[k], t1[k], err_msg=k)
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    np.testing.assert_array_equal(out[0][3], out[1][3])
