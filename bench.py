@@ -2,19 +2,29 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3h|cfg3t|cfg4|cfg4s|cfg5|cfg5h|cfg5t]
 
-One process per GPU (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE).  A step is one full batched
-search over the rank's trees with inputs resident in HBM: root inference + root preparation
-(1 launch), all simulations with in-kernel leaf evaluation (1 launch), final action rule
-(1 launch).  Weak scaling: every rank searches its own B trees; there is no data-path collective.
+One process per GPU.  Under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (torchrun) the process is
+one rank; started plainly with --gpus N > 1 it starts the N ranks itself, as fresh child processes, before
+anything in it has touched a GPU, and exits with their status.  A step is one full batched search over the
+rank's trees with inputs resident in HBM: root inference + root preparation, all simulations with in-kernel
+leaf evaluation (one launch), final action rule.  Weak scaling: every rank searches its own B trees; there is
+no data-path collective inside a search (self-play gathers each move's records on rank 0).
 
-Default workload = BASELINE.json configs[1]: CartPole, 256 envs x 50 simulations, PUCT,
-random-init MuZeroFullyConnectedNetwork (encoding 8, hidden layers [16], support 21).
+K steps are timed as one block bracketed by barrier + synchronize; when a block is shorter than a second the
+block is repeated (same K, same bracketing) until a second of timed work has accumulated, and the figures are
+taken over all blocks (`timed_blocks`, `timed_region_s` in the output line).
+
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration: TicTacToe, 16384 trees x
+100 simulations, Gumbel sequential halving, random-init MuZeroResidualNetwork (1 block, 16 channels) evaluated
+on the matrix cores inside the search kernel.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -81,19 +91,70 @@ def algorithmic_bytes(node_visits_total, B, S, A, H, gumbel):
     return levels * (36 + 6 * w + A * (4 + p + 2 * w)) + B * S * (8 * H + p * A + 20 + 3 * w)
 
 
-def main():
+DEFAULT_STEPS = {'cfg1': 200, 'cfg2': 2000, 'cfg3': 100, 'cfg3h': 200, 'cfg3t': 3, 'cfg4': 500, 'cfg4s': 500,
+                 'cfg5': 50, 'cfg5h': 200, 'cfg5t': 5}
+MIN_TIMED_S = 1.0     # repeat the block of K steps until this much timed work has accumulated
+MAX_BLOCKS = 200
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--lanes', type=int, default=0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = DEFAULT_STEPS[args.workload]
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        ap.error('--gpus and --steps must be positive, --warmup non-negative')
+    return args
 
+
+def launch_ranks(n: int) -> int:
+    """Starts n ranks of this script as child processes (one per GPU) and waits for them.  Called before this
+    process has made any GPU call: the children are fresh processes, nothing is re-executed in place.
+    Rank 0's standard output is this process's; the exit status is the first non-zero child status."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    status = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc
+                for q in pending:           # a rank failed: the others would wait in a collective for ever
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return status
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank, world = mzdist.init()
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}', file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get('MUZERO_AMD_BENCH_STUB') == '1':
+        return run_stub(args, rank, world)
     _, local_rank, _ = mzdist.env_rank_world()
-    torch.cuda.set_device(local_rank % torch.cuda.device_count() if world > 1 else 0)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dev = torch.device('cuda', torch.cuda.current_device())
 
     from muzero_amd.engine import SearchEngine
@@ -108,6 +169,8 @@ def main():
     tree_id0 = rank * B
     packed = None
     sp = None
+    gatherer = None
+    net = None
     if leaf == 'dropin':
         sys.path.insert(0, os.path.join(REPO, 'muzero_amd'))
         from mcts.mcts import MCTS  # the drop-in package, imported under the reference's name
@@ -128,6 +191,8 @@ def main():
         H = packed.H
         sp = BatchedSelfPlay(cfg, 'cartpole', net, B, seed=rank, tree_id0=tree_id0, device=dev)
         eng = sp.engine
+        # every move's records (action, root value, policy, observation, reward, done, to_play) to rank 0
+        gatherer = mzdist.StepGather(B, {'probs': A, 'obs_before': sp.envs.obs_size}, device=dev, dst=0)
     elif leaf == 'mlp':
         torch.manual_seed(0)
         net = MuZeroNetwork(cartpole_net_config(), seed=0)
@@ -153,9 +218,7 @@ def main():
         pm_io = pack_network_mfma(net)
         leaf_macs = (pm_io[0].macs, pm_io[0].padded_macs)
         eng.set_network_mfma(*pm_io)
-        boards = rng.integers(0, 3, size=(B, 9)) - 1  # random (not necessarily reachable) positions
-        planes = np.stack([(boards == -1), (boards == 1), np.ones_like(boards) * -1], axis=1).astype(np.float32)
-        obs = torch.as_tensor(planes.reshape(B, 27), device=dev)
+        obs = torch.as_tensor(tictactoe_roots(rng, B).reshape(B, 27), device=dev)
     else:
         H = 144 if A == 9 else 256
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
@@ -194,8 +257,7 @@ def main():
             out = sp.step(temperature)
             if i is not None:
                 ev[i][1].record()
-            if world > 1:  # trajectories of this move to the replay rank
-                mzdist.gather_root_stats(out['action'], out['value'], out['probs'])
+            gatherer.gather(out)  # this move's records to the replay rank (a no-op on one rank)
             return out
         if leaf == 'mlp' and reg_tree and one_call == 'move':   # roots, simulations, final action rule: one call
             if i is not None:
@@ -244,24 +306,32 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    mzdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    mzdist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = mzdist.max_over_ranks(elapsed, mzdist.reduce_device(dev))
+    rdev = mzdist.reduce_device(dev)
+    elapsed, kern_ms_all, blocks = 0.0, [], 0
+    while True:
+        torch.cuda.synchronize()
+        mzdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        mzdist.barrier()
+        block = mzdist.max_over_ranks(time.perf_counter() - t0, rdev)   # the same number on every rank
+        elapsed += block
+        blocks += 1
+        kern_ms_all += [a.elapsed_time(b) for a, b in ev]
+        if elapsed >= MIN_TIMED_S or blocks >= MAX_BLOCKS:
+            break
+    n_steps = blocks * args.steps
 
     nv, _ = eng.stats()
     node_visits = int(nv.sum().item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean(kern_ms_all))
     alg = algorithmic_bytes(node_visits, B, S, A, H, gumbel)
     achieved = alg / (kern_ms * 1e-3) / 1e9
-    sims = world * B * S * args.steps
-    nv_all = mzdist.sum_over_ranks(node_visits, mzdist.reduce_device(dev))
+    sims = world * B * S * n_steps
+    nv_all = mzdist.sum_over_ranks(node_visits, rdev)
 
     traffic = None
     try:  # HBM bytes per launch from the PMC counters, measured offline with rocprofv3 (profiles/hbm_traffic.json)
@@ -271,22 +341,21 @@ def main():
         pass
     out = {
         'metric': 'MCTS simulations/sec', 'value': sims / elapsed, 'unit': 'simulations/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / n_steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-        'data': 'synthetic', 'config': {'workload': desc, 'trees_per_gpu': B, 'simulations': S, 'n_actions': A,
-                                        'rule': 'gumbel' if gumbel else 'puct', 'leaf_eval': leaf,
+        'data': 'synthetic', 'config': {'workload': desc, 'name': args.workload, 'trees_per_gpu': B, 'simulations': S,
+                                        'n_actions': A, 'rule': 'gumbel' if gumbel else 'puct', 'leaf_eval': leaf,
                                         'lanes_per_tree': eng and int(args.lanes)},
-        'node_visits_per_sec': nv_all * args.steps / elapsed,
+        'timed_blocks': blocks, 'timed_region_s': elapsed,
+        'node_visits_per_sec': nv_all * n_steps / elapsed,
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
-        'env_steps_per_sec': (world * B * args.steps / elapsed) if leaf == 'selfplay' else None,
+        'env_steps_per_sec': (world * B * n_steps / elapsed) if leaf == 'selfplay' else None,
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
                                 'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
-                     'limiter': 'not HBM: the shader-sequencer counters (profiles/round1_final_sq_counters.txt) show the '
-                                'large-batch tree kernels at ~80% of the VALU issue rate; the 256-tree search is one wave per '
-                                'tree with the tree in registers, ~1000 dependent instructions per simulation at ~4.7 cycles each'},
+                     'limiter': LIMITER.get(leaf, LIMITER['tree'])},
     }
 
     if leaf in ('mfma', 'mfma_step') and leaf_macs is not None:
@@ -296,10 +365,9 @@ def main():
         out['roofline_mfma'] = {'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                 'frac': tf / MFMA_F32_PEAK_TFLOPS, 'flop_per_leaf': 2 * leaf_macs[0],
                                 'executed_flop_per_leaf': 2 * leaf_macs[1],
-                                'note': 'the launch also holds the tree operations of the same simulations; MFMA busy cycles '
-                                        'from the counters: profiles/round1_final_mfma_counters.txt'}
+                                'note': 'the launch also holds the tree operations of the same simulations'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg, packed, leaf, A, S, H, B, gumbel)
+        out['cpu_baseline'] = cpu_baseline(cfg, net, leaf, A, S, H, B, gumbel)
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
@@ -307,39 +375,100 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(cfg, packed, leaf, A, S, H, B, gumbel, budget_s=8.0):
-    """The CPU checker (oracle/, a C port of the reference's search) timed on this box's host
-    cores on the same workload: whole batches repeated until the time budget is used."""
+LIMITER = {
+    'tree': 'not HBM: the shader-sequencer counters show the large-batch tree kernels at 70-85% of the VALU issue rate '
+            '(float64 arithmetic in the reference\'s operation order); small batches are one wave per tree, bound by the '
+            'latency of ~1000 dependent instructions per simulation',
+    'mfma': 'per simulation a block alternates between the descent (dependent record reads, one per tree level), the '
+            'float32 matrix-core network of its tile and the float64 backup; neither HBM nor the matrix pipes saturate',
+}
+
+
+def tictactoe_roots(rng, B):
+    """Observations (planes: X stones, O stones, side to move) of B random TicTacToe positions."""
+    boards = rng.integers(0, 3, size=(B, 9)) - 1  # random (not necessarily reachable) positions
+    return np.stack([(boards == -1), (boards == 1), np.ones_like(boards) * -1], axis=1).astype(np.float32)
+
+
+def run_stub(args, rank, world):
+    """MUZERO_AMD_BENCH_STUB=1: everything around the search (rank start-up, process group, barriers, the
+    max-over-ranks clock, the per-move gather, rank 0's output line) with an empty step and no GPU, so that the
+    multi-rank plumbing can be tested on hosts without one.  The line says so in `data`."""
+    B, A, OBS = 64 + rank, 2, 4   # uneven shards on purpose
+    g = mzdist.StepGather(B, {'probs': A, 'obs_before': OBS}, device='cpu', dst=0)
+    rec = dict(action=torch.zeros(B, dtype=torch.int32), value=torch.zeros(B, dtype=torch.float64),
+               probs=torch.zeros((B, A), dtype=torch.float64), obs_before=torch.zeros((B, OBS)),
+               reward=torch.zeros(B), done=torch.zeros(B, dtype=torch.uint8), to_play=torch.zeros(B, dtype=torch.int32))
+    gathered = 0
+    for _ in range(args.warmup):
+        g.gather(rec)
+    mzdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = g.gather(rec)
+        gathered = 0 if full is None else int(full['action'].shape[0])
+    mzdist.barrier()
+    elapsed = mzdist.max_over_ranks(time.perf_counter() - t0)
+    total = int(mzdist.sum_over_ranks(B))
+    if rank == 0:
+        assert gathered == total, (gathered, total)
+        print(json.dumps({'metric': 'MCTS simulations/sec', 'value': 0.0, 'unit': 'simulations/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+                          'data': 'stub (no search executed)', 'config': {'workload': 'stub', 'gathered_rows': gathered}}),
+              flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(cfg, net, leaf, A, S, H, B, gumbel, budget_s=10.0):
+    """The CPU checker (oracle/, a C port of the reference's search) timed on this box's host cores on a
+    bounded sample of the SAME workload - same rule, simulations, action count and leaf evaluator (the lowered
+    network executed as a dense program; the hash network for the hash workloads): batches of trees, one tree
+    per OpenMP thread, repeated until the time budget is used."""
     from oracle import oracle as orc
     from muzero_amd import hashnet
-    from muzero_amd.network import MuZeroNetwork
-    threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or min(16, os.cpu_count() or 1)
-    threads = max(1, min(threads, 16))
+    from muzero_amd.packing import pack_network
+    threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or (os.cpu_count() or 1)
     rng = np.random.default_rng(1)
-    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
-    di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
-    g = rng.gumbel(size=(B, A)) if gumbel else None
-    if leaf in ('mlp', 'selfplay'):
-        net = MuZeroNetwork(cartpole_net_config(), seed=0)
-        obs = rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32)
-        lg, hid, val = net.initial_inference(torch.as_tensor(obs))
+    kind = 'hash network'
+    if leaf in ('mlp', 'selfplay', 'mfma', 'step', 'mfma_step', 'step5', 'dropin'):
+        cpu_net = net.to('cpu') if hasattr(net, 'to') else net
+        packed = pack_network(cpu_net)
+        # a batch that takes on the order of a second: ~2 ns per multiply-accumulate and thread
+        per_tree = S * max(packed.recurrent.macs, 1) * 2e-9
+        n = int(min(B, max(threads, math.ceil(1.0 * threads / per_tree))))
+        if leaf in ('mlp', 'selfplay'):
+            obs = rng.uniform(-0.05, 0.05, size=(n, 4)).astype(np.float32)
+        elif A == 9:
+            obs = tictactoe_roots(rng, n).reshape(n, 27)
+        else:
+            obs = rng.standard_normal((n, 128)).astype(np.float32)
+        with torch.no_grad():
+            lg, hid, val = cpu_net.initial_flat(torch.as_tensor(obs))
+        legal, tp = np.ones((n, A)), np.zeros(n, np.int32)
+        di = None if gumbel else rng.dirichlet([0.25] * A, size=n)
+        g = rng.gumbel(size=(n, A)) if gumbel else None
         run = lambda: orc.search_batch_net(cfg, packed, lg.numpy(), hid.numpy(), val.numpy(), legal, tp, dirichlet=di,  # noqa: E731
                                            frac=0.25, gumbel=g, seed=0, n_threads=threads)
+        kind = 'the same lowered network as a dense float32 program'
     else:
         hp = hashnet.HashNetParams(A, H, 4, 1, 1)
         n = min(B, 2048)
+        legal, tp = np.ones((n, A)), np.zeros(n, np.int32)
+        di = None if gumbel else rng.dirichlet([0.25] * A, size=n)
+        g = rng.gumbel(size=(n, A)) if gumbel else None
         codes = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
-        B = n
-        run = lambda: orc.search_batch_hash(cfg, hp, H, codes, legal[:n], tp[:n], dirichlet=None if di is None else di[:n],  # noqa: E731
-                                            frac=0.25, gumbel=None if g is None else g[:n], seed=0, n_threads=threads)
+        run = lambda: orc.search_batch_hash(cfg, hp, H, codes, legal, tp, dirichlet=di, frac=0.25, gumbel=g, seed=0,  # noqa: E731
+                                            n_threads=threads)
     run()
     reps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         r = run()
         reps += 1
     dt = time.perf_counter() - t0
-    return {'value': reps * B * S / dt, 'unit': 'simulations/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{reps} batches of {B} trees x {S} sims ({dt:.1f} s), one tree per OpenMP thread',
+    return {'value': reps * n * S / dt, 'unit': 'simulations/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{reps} batches of {n} trees x {S} sims ({dt:.1f} s), leaves: {kind}; one tree per OpenMP thread',
             'node_visits_per_sec': reps * float(r.node_visits.sum()) / dt}
 
 

@@ -84,6 +84,13 @@ mz_ctx *mz_create(const mz_config *cfg);
 void mz_destroy(mz_ctx *ctx);
 const char *mz_last_error(void);
 
+/* Key of the counter-based tie-break noise (MZ_NOISE_COUNTER) for the searches that follow: stands for the
+ * position of the global np.random stream at the start of a reference search (mcts/action_selection.py:46 draws
+ * from it), which a caller of the reference moves with np.random.seed / utils/utils.py:28-31 set_seed.
+ * mz_create sets it from mz_config.seed; callers that search the same trees move after move pass a new key per
+ * move so that no two searches replay the same uniforms. */
+int mz_set_seed(mz_ctx *ctx, uint64_t seed);
+
 /* Replaces add_exploration_noise (mcts/mcts.py:22-31) + mask_illegal_action_logits
  * (utils/game_utils.py:71-78) for B roots.  logits f32[B][A]; dirichlet f64[B][A] (PUCT) or NULL
  * (Gumbel); legal u8[B][A]; out_prior f64[B][A] (PUCT) / f32[B][A] (Gumbel).
@@ -196,6 +203,12 @@ int mz_search_move(mz_ctx *ctx, int32_t B, const float *obs, const uint8_t *lega
 /* Copies tree b to host arrays (synchronises `stream`).  Nodes not yet expanded read as a fresh
  * tree's (mcts/mcts.py:72-92). */
 int mz_tree_export(mz_ctx *ctx, int32_t b, mz_tree_host *out_h, void *stream);
+
+/* Waits for `stream` and reports what kernels flagged since the last check: MZ_ERR_DEVICE when a selection state
+ * was inconsistent, or when a search made more PUCT selection calls than the MZ_NOISE_BUFFER given to it holds
+ * rows (the reference would have drawn further uniforms, mcts/action_selection.py:46; the engine used 0).  The
+ * other entry points never synchronise; mz_tree_export and mz_node_backward run the same check. */
+int mz_check(mz_ctx *ctx, void *stream);
 
 /* Per-tree counters since the last reset: node_visits i64[B] = sum(node_visits) - 1
  * (device or NULL), noise_calls i32[B] (device or NULL). */

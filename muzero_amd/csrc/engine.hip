@@ -10,7 +10,9 @@
 #include <type_traits>
 #include <vector>
 
-#include <unordered_map>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "../../include/muzero_amd.h"
 #include "tree_kernels.h"  // device_common.h, tree_ops.h
 #include "dense_net.h"
@@ -219,6 +221,14 @@ extern "C" void mz_destroy(mz_ctx *c)
     delete c;
 }
 
+extern "C" int mz_set_seed(mz_ctx *c, uint64_t seed)
+{
+    if (!c) return fail(MZ_ERR_ARG, "mz_set_seed: null context");
+    c->cfg.seed = seed;
+    c->d.seed = seed;   // kernels receive the context's device descriptor by value at every launch
+    return MZ_OK;
+}
+
 // Calls f(lanes tag, action-lanes tag, gumbel tag) for the (lanes per tree, action lanes, rule) of a context.
 // Supported shapes: a group is either exactly the action lanes, or 16 or 64 lanes.
 template <int N> using ic = std::integral_constant<int, N>;
@@ -260,13 +270,19 @@ static int check_ctx(mz_ctx *c, const char *fn)
 }
 
 // hipFuncSetAttribute costs microseconds of host time per call: the dynamic LDS limit of a kernel is raised only when
-// a launch needs more than an earlier one was granted (one device per process: the limit is per device and function).
+// a launch needs more than an earlier one was granted.  The limit belongs to (device, function), and contexts of several
+// devices or host threads may launch at once, hence the key and the lock.
 static hipError_t ensure_dynamic_lds(const void *kern, size_t bytes)
 {
-    static std::unordered_map<const void *, size_t> granted;
-    size_t &g = granted[kern];
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &g = granted[{dev, kern}];
     if (bytes <= g) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess) g = bytes;
     return e;
 }
@@ -588,9 +604,17 @@ static int device_error(mz_ctx *c, hipStream_t st, const char *fn)
     HIPCHK(hipStreamSynchronize(st));
     if (e) {
         (void)hipMemsetAsync(c->d.err, 0, 4, st);
-        return fail(MZ_ERR_DEVICE, std::string(fn) + ": a kernel reported an inconsistent selection state");
+        return fail(MZ_ERR_DEVICE, std::string(fn) + (e == 2 ? ": a search made more PUCT selection calls than the noise buffer holds rows"
+                                                              : ": a kernel reported an inconsistent selection state"));
     }
     return MZ_OK;
+}
+
+extern "C" int mz_check(mz_ctx *c, void *stream)
+{
+    int rc = check_ctx(c, "mz_check");
+    if (rc) return rc;
+    return device_error(c, (hipStream_t)stream, "mz_check");
 }
 
 extern "C" int mz_tree_export(mz_ctx *c, int32_t b, mz_tree_host *o, void *stream)
@@ -967,6 +991,11 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
     if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no pending selection (call mz_select first)");
     if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no network uploaded (call mz_set_network_mfma first)");
     int leaf = c->n_expanded + 1;
+    select_next = select_next && leaf < c->cfg.n_simulations;
+    if (select_next) {   // checked before anything is launched: a rejected call leaves the pending selection as it was
+        if ((rc = check_noise(c, noise, noise_max_calls, "mz_expand_backup_net"))) return rc;
+        if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
+    }
     // 32 trees per block while their activations fit in LDS, else 16; batches that would leave most CUs
     // without a tile (and networks whose tile does not fit at all) go level by level through global memory
     const int tm = (size_t)c->mnet.stride * 32 * 4 <= 160 * 1024 ? 32 : 16;
@@ -1005,10 +1034,7 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
                            c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
     }
     if ((rc = launch_status("mz_expand_backup_net"))) return rc;
-    select_next = select_next && leaf < c->cfg.n_simulations;
     if (select_next) {
-        if ((rc = check_noise(c, noise, noise_max_calls, "mz_expand_backup_net"))) return rc;
-        if (c->cfg.noise_mode != MZ_NOISE_BUFFER) noise = nullptr;
         MZ_LAUNCH(c, k_backup_select, false, c->B, 0, stream, c->d, leaf, (const float *)c->leaf_logits,
                   (const double *)c->leaf_value, (const double *)c->leaf_reward, noise, (int)noise_max_calls);
     } else {

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int
     }
 #endif
     if (live && a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        if constexpr (!GUMBEL) store_noise_calls(d, t, calls, noise_max_calls);
         d.visit_total[t] += visited;
     }
 }

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_net(Dev d, NetDev net, int 
         MZ_STAMP(st_bk)
     }
     if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        if constexpr (!GUMBEL) store_noise_calls(d, t, calls, noise_max_calls);
         d.visit_total[t] += visited;
     }
     if constexpr (TREE_LDS) {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
 #endif
     }
     if (lane == 0) {
-        d.noise_calls[t] = calls;
+        store_noise_calls(d, t, calls, noise_max_calls);
         d.visit_total[t] += visited;
     }
     // ---- write the tree back

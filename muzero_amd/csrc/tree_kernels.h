@@ -121,7 +121,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_select(Dev d, const double *noise,
     int parent = descend<LANES, RL, GUMBEL>(d, dc, tree_mem(d, t), a, on, nz, noise_max_calls, calls, &action, &ntp,
                                             &depth);
     if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        if constexpr (!GUMBEL) store_noise_calls(d, t, calls, noise_max_calls);
         d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
         if (out_parent) out_parent[t] = parent;
         if (out_action) out_action[t] = action;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_backup_select(Dev d, int leaf, con
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
     parent = descend<LANES, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
     if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        if constexpr (!GUMBEL) store_noise_calls(d, t, calls, noise_max_calls);
         d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
     }
 }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_hash(Dev d, HashNet hn, int
         __threadfence_block();  // this group's stores are read by its other lanes in the next descent
     }
     if (a == 0) {
-        if constexpr (!GUMBEL) d.noise_calls[t] = calls;
+        if constexpr (!GUMBEL) store_noise_calls(d, t, calls, noise_max_calls);
         d.visit_total[t] += visited;
     }
 }

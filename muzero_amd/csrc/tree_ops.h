@@ -136,6 +136,15 @@ __device__ __forceinline__ double gumbel_score(const NodeStats &s, bool on, doub
     return sc + (s.cv == considered ? 0.0 : -__builtin_huge_val());
 }
 
+// End of a kernel's descents: the tree's running count of PUCT selection calls.  A caller-supplied noise buffer
+// (MZ_NOISE_BUFFER) shorter than the calls made is reported through the device error flag - the calls past its
+// end were scored with u = 0, which is not what the caller asked for.
+__device__ __forceinline__ void store_noise_calls(const Dev &d, int t, uint32_t calls, int noise_max_calls)
+{
+    d.noise_calls[t] = calls;
+    if (d.noise_mode == 1 && (long long)calls > (long long)noise_max_calls) atomicExch(d.err, 2);
+}
+
 // Per-descent constants hoisted out of the level loop.
 struct DescendCtx {
     unsigned long long legal;     // root legality mask of the tree

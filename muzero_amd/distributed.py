@@ -65,22 +65,83 @@ def sum_over_ranks(value: float, device='cpu') -> float:
     return float(t.item())
 
 
+# The per-move record of self-play: the fields of the reference's GameHistory.save call (self_play.py:107-109,
+# games/game.py:99-112) plus the episode-end flag.  Ordered by falling element size so that every field
+# starts aligned inside the packed byte buffer.
+RECORD_FIELDS = (('value', torch.float64), ('probs', torch.float64), ('obs_before', torch.float32),
+                 ('reward', torch.float32), ('action', torch.int32), ('to_play', torch.int32), ('done', torch.uint8))
+
+
+class StepGather:
+    """Gathers every rank's per-move records on the replay rank `dst` (global tree order).
+
+    One `gather` collective per move (RCCL send/recv over xGMI on GPUs; gloo on the host in the CPU tests)
+    of one packed byte buffer per rank: field-major, every field padded to the largest shard so ranks with
+    uneven shards (`shard_range` gives the first ranks one tree more) exchange equal sizes.  Shard sizes are
+    exchanged once, at construction; buffers are allocated once and reused, so a move costs D2D copies into
+    the send buffer and the collective.  Fields absent from a record (search-only callers have no
+    observation / reward / done) travel as zeros.
+
+    b: trees of this rank; widths: columns of the 2-D fields, e.g. {'probs': A, 'obs_before': obs_size}."""
+
+    def __init__(self, b: int, widths: dict, device='cpu', dst: int = 0):
+        self.b, self.dst = int(b), int(dst)
+        self.widths = {name: int(widths.get(name, 1)) for name, _ in RECORD_FIELDS}
+        self.active = dist.is_initialized() and dist.get_world_size() > 1
+        self.out_device = device
+        if not self.active:
+            self.sizes = [self.b]
+            return
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device if dist.get_backend() == 'nccl' else 'cpu'
+        mine = torch.tensor([self.b], dtype=torch.int64, device=self.device)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        self.sizes = [int(x.item()) for x in every]
+        self.rows = (max(self.sizes) + 7) // 8 * 8
+        self.offsets, off = {}, 0
+        for name, dtype in RECORD_FIELDS:
+            self.offsets[name] = off
+            off += self.rows * self.widths[name] * torch.empty(0, dtype=dtype).element_size()
+        self.nbytes = off
+        self.send = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.recv = ([torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+                     if self.rank == self.dst else None)
+
+    def _field(self, buf: torch.Tensor, name: str, dtype) -> torch.Tensor:
+        n = self.rows * self.widths[name] * torch.empty(0, dtype=dtype).element_size()
+        return buf[self.offsets[name]:self.offsets[name] + n].view(dtype).reshape(self.rows, self.widths[name])
+
+    def gather(self, record: dict):
+        """record: name -> tensor with leading dimension b (RECORD_FIELDS names; missing ones are sent as zeros).
+        Returns on `dst` a dict name -> tensor over all ranks' trees in rank order, None on the other ranks."""
+        if not self.active:
+            return {name: record[name] for name, _ in RECORD_FIELDS if name in record}
+        for name, dtype in RECORD_FIELDS:
+            x = record.get(name)
+            if x is not None:
+                self._field(self.send, name, dtype)[:self.b].copy_(x.reshape(self.b, self.widths[name]), non_blocking=True)
+        dist.gather(self.send, self.recv, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        out = {}
+        for name, dtype in RECORD_FIELDS:
+            if name not in record:
+                continue
+            parts = [self._field(self.recv[r], name, dtype)[:self.sizes[r]] for r in range(self.world)]
+            full = torch.cat(parts, dim=0).to(self.out_device)
+            out[name] = full if record[name].dim() > 1 else full.reshape(-1)
+        return out
+
+
 def gather_root_stats(action: torch.Tensor, root_value: torch.Tensor, probs: torch.Tensor, dst: int = 0):
-    """Gathers each rank's (action i32[b], root_value f64[b], probs f64[b, A]) on `dst`, in rank
-    order (= global tree order for equal shards).  One packed all_gather: latency-bound, a few KB
-    to a few hundred KB per step.  Returns the concatenated tensors on `dst`, None elsewhere."""
+    """One-off form of StepGather for a search's root statistics: (action i32[b], root_value f64[b],
+    probs f64[b, A]) of every rank on `dst`, in rank order; None on the other ranks.  Shards may be uneven."""
     if not dist.is_initialized():
         return action, root_value, probs
-    b, A = probs.shape
-    packed = torch.cat([action.to(torch.float64).reshape(b, 1), root_value.reshape(b, 1), probs], dim=1).contiguous()
-    if dist.get_backend() != 'nccl':
-        packed = packed.cpu()
-    out = [torch.empty_like(packed) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, packed)
-    if dist.get_rank() != dst:
-        return None
-    full = torch.cat(out, dim=0).to(probs.device)
-    return full[:, 0].to(torch.int32), full[:, 1].contiguous(), full[:, 2:].contiguous()
+    g = StepGather(probs.shape[0], {'probs': probs.shape[1]}, device=probs.device, dst=dst)
+    out = g.gather({'action': action, 'value': root_value, 'probs': probs})
+    return None if out is None else (out['action'], out['value'], out['probs'])
 
 
 def broadcast_weights(state_dict: dict, src: int = 0, device=None) -> dict:

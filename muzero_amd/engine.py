@@ -49,7 +49,7 @@ class MzEnvState(C.Structure):
 
 ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
-EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
+EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_set_seed', 'mz_check', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
            'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
@@ -69,6 +69,8 @@ def lib():
         L.mz_destroy.restype = None
         L.mz_last_error.restype = C.c_char_p
         vp, i32, f64, u64 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64
+        L.mz_set_seed.argtypes = [vp, u64]
+        L.mz_check.argtypes = [vp, vp]
         L.mz_root_prepare.argtypes = [vp, i32, vp, vp, f64, vp, i32, vp, vp]
         L.mz_node_backward.argtypes = [vp, i32, i32, i32, vp]
         L.mz_tree_reset.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64, vp]
@@ -172,6 +174,7 @@ class SearchEngine:
             msg = lib().mz_last_error().decode()
             raise ValueError(msg) if 'mz_create:' in msg and 'hip' not in msg.lower() else EngineError(msg)
         self.B = 0
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.prior_dtype = torch.float32 if g else torch.float64
         self._parent = self._action = self._phid = None
 
@@ -185,6 +188,11 @@ class SearchEngine:
             self.close()
         except Exception:
             pass
+
+    def set_seed(self, seed: int):
+        """Key of the counter-based tie-break noise for the searches that follow."""
+        _check(lib().mz_set_seed(self._ctx, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)))
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, x, dtype, shape=None):
@@ -393,6 +401,11 @@ class SearchEngine:
                                      _ptr(out['action']), _ptr(out['probs']), _ptr(out['value']),
                                      _ptr(out.get('obs_before')), _ptr(out['reward']), _ptr(out['done']),
                                      _ptr(out['to_play']), _stream()))
+
+    def check(self):
+        """Waits for the stream and raises EngineError if a kernel flagged an inconsistent state or a noise
+        buffer shorter than the selection calls a search made."""
+        _check(lib().mz_check(self._ctx, _stream()))
 
     def stats(self):
         nv = torch.empty(self.B, dtype=torch.int64, device=self.device)

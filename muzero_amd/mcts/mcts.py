@@ -52,6 +52,8 @@ class MCTS:
                 eng.close()
             eng = _engine.SearchEngine(self.config, hidden_size, max(batch, 1), noise_mode=noise_mode, seed=seed)
             self._engines[key] = eng
+        if eng.seed != (int(seed) & 0xFFFFFFFFFFFFFFFF):
+            eng.set_seed(seed)   # the engine is reused across searches, the noise key is per search
         return eng
 
     # ------------------------------------------------------------------ search
@@ -193,6 +195,7 @@ class MCTS:
         u = None
         if not gumbel:
             if rng_state is not None:
+                eng.check()
                 _, calls = eng.stats()
                 np.random.set_state(rng_state)
                 for n in calls.cpu().numpy():  # advance past the rows the search used

@@ -36,3 +36,9 @@ def noise_u(seed: int, tree: int, call: int, action: int) -> float:
 
 def noise_row(seed: int, tree: int, call: int, n_actions: int) -> np.ndarray:
     return np.array([noise_u(seed, tree, call, a) for a in range(n_actions)], dtype=np.float64)
+
+
+def move_seed(seed: int, move: int) -> int:
+    """Noise key of the `move`-th search of a run that searches the same trees again and again (self-play):
+    a different, reproducible key per move, so that tree b does not replay the uniforms of its previous search."""
+    return splitmix64((seed + move * 0xA0761D6478BD642F) & _M64) if move else seed & _M64

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import engine as _engine
+from . import noise as _noise
 from .games.game import GameHistory
 
 
@@ -145,6 +146,8 @@ class BatchedSelfPlay:
         e, cfg, eng = self.envs, self.config, self.engine
         dirichlet, g = root_noise if root_noise is not None else self._root_noise()
         frac = 0.0 if self.gumbel else cfg.exploration_frac
+        if eng is not None and not self.gumbel and self._noise_mode == _engine.NOISE_COUNTER:
+            eng.set_seed(_noise.move_seed(self._seed, self.steps_done))   # fresh tie-break uniforms every move
         if self.mode == 'fused':
             eng.begin_net(e.search_obs, e.legal, e.to_play, dirichlet, frac, g, tree_id0=self.tree_id0)
             eng.search_net(noise)

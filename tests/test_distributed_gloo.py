@@ -22,15 +22,32 @@ def _worker(rank, world, port, out_dir):
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     r, w = mzdist.init('gloo')
     assert (r, w) == (rank, world)
-    B_total, A = 10, 3
+    B_total, A, OBS = 11, 3, 4          # 11 trees over 2 ranks: uneven shards (6 and 5)
     lo, hi = mzdist.shard_range(B_total, rank, world)
     b = hi - lo
     # every rank's slice of a global, rank-independent result
     g_action = torch.arange(B_total, dtype=torch.int32)
     g_value = torch.arange(B_total, dtype=torch.float64) * 0.5
     g_probs = torch.arange(B_total * A, dtype=torch.float64).reshape(B_total, A)
-    assert b == 5
+    g_obs = torch.arange(B_total * OBS, dtype=torch.float32).reshape(B_total, OBS) * 0.25
+    g_reward = torch.arange(B_total, dtype=torch.float32) - 3.0
+    g_done = (torch.arange(B_total) % 3 == 0).to(torch.uint8)
+    g_tp = (torch.arange(B_total) % 2).to(torch.int32)
+    assert b == (6 if rank == 0 else 5)
     res = mzdist.gather_root_stats(g_action[lo:hi], g_value[lo:hi], g_probs[lo:hi], dst=0)
+    # the whole per-move record of self-play, twice through the same (preallocated) exchange
+    sg = mzdist.StepGather(b, {'probs': A, 'obs_before': OBS}, device='cpu', dst=0)
+    assert sg.sizes == [6, 5]
+    full = dict(action=g_action, value=g_value, probs=g_probs, obs_before=g_obs, reward=g_reward, done=g_done,
+                to_play=g_tp)
+    for rep in range(2):
+        rec = sg.gather({k: (v + rep if k != 'done' else v)[lo:hi] for k, v in full.items()})
+        if rank == 0:
+            for k, v in full.items():
+                want = v + rep if k != 'done' else v
+                assert rec[k].dtype == v.dtype and torch.equal(rec[k], want), k
+        else:
+            assert rec is None
     mzdist.barrier()
     slow = mzdist.max_over_ranks(1.0 + rank)
     total = mzdist.sum_over_ranks(float(b))

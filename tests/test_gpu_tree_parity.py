@@ -3,6 +3,7 @@
 Bit-exact on every tree field, visit count, action and root value; the returned policy is compared
 at rtol 1e-12 because it ends in a float64 exp whose last bit differs between math libraries.
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -363,4 +364,71 @@ def test_nan_regime_matches_reference():
         np.testing.assert_allclose(p[~np.isnan(p)], z['probs'][~np.isnan(z['probs'])], rtol=1e-12, atol=1e-300)
         for b in range(B):
             assert np.array_equal(eng.export_tree(b)['children_visits'][0], z['root_visits'][b]), (lanes, b)
+        eng.close()
+
+
+def test_noise_key_follows_the_seed_of_each_search():
+    """One engine, two searches with different noise keys (mz_set_seed): each equals the checker run with its
+    own key, and the keys give different tie-break draws.  MCTS.search_batch re-keys its cached engine."""
+    from oracle import oracle as orc
+    from muzero_amd import noise as mznoise
+    rng = np.random.default_rng(5)
+    A, S, H, B = 2, 40, 4, 256      # two actions with near-equal priors: ties are frequent
+    cfg = make_config(False, A, S, 1, 0.997)
+    hp = hashnet.HashNetParams(A, H, 9, 0, 1)
+    codes, legal = _batch_inputs(A, B, rng)
+    to_play = np.zeros(B, np.int32)
+    dirichlet = np.full((B, A), 0.5)
+    logits = np.zeros((B, A), np.float32)
+    eng = _engine(cfg, H, B, seed=3)
+    seen = {}
+    for seed in (3, 11):
+        ref = orc.search_batch_hash(cfg, hp, H, codes, legal, to_play, dirichlet=dirichlet, frac=0.25, seed=seed,
+                                    tree_id0=7, n_threads=4)
+        if seed != 3:
+            eng.set_seed(seed)
+        prior = eng.root_prepare(logits, legal, dirichlet, 0.25)
+        eng.reset(prior, [hashnet.value_of(int(c)) for c in codes], np.stack([hashnet.hidden_of(int(c), hp) for c in codes]),
+                  to_play, legal, None, tree_id0=7)
+        eng.search_hash(9, 0, 1)
+        nv, _ = eng.stats()
+        assert np.array_equal(nv.cpu().numpy(), ref.node_visits), seed
+        seen[seed] = np.stack([eng.export_tree(b)['children_visits'][0] for b in range(32)])
+        assert np.array_equal(seen[seed], ref.root_visits[:32]), seed
+    assert not np.array_equal(seen[3], seen[11])
+    eng.close()
+    assert mznoise.noise_u(3, 7, 0, 0) != mznoise.noise_u(11, 7, 0, 0)
+    # the drop-in's engine cache: same engine object, new key
+    sys_path_mcts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'muzero_amd')
+    import sys
+    sys.path.insert(0, sys_path_mcts)
+    from mcts.mcts import MCTS
+    from muzero_amd.engine import NOISE_COUNTER
+    m = MCTS(cfg)
+    e1 = m._engine_for(H, 4, NOISE_COUNTER, seed=1)
+    e2 = m._engine_for(H, 4, NOISE_COUNTER, seed=2)
+    assert e1 is e2 and e2.seed == 2
+    e1.close()
+
+
+def test_short_noise_buffer_is_reported():
+    """A PUCT search that makes more selection calls than the caller's noise buffer has rows raises at the next
+    check instead of silently scoring with zero noise."""
+    from muzero_amd.engine import NOISE_BUFFER, EngineError
+    A, S, H, B = 3, 12, 2, 4
+    cfg = make_config(False, A, S, 1, 0.99)
+    hp = hashnet.HashNetParams(A, H, 4, 1, 1)
+    codes = np.arange(1, B + 1, dtype=np.uint32)
+    for rows, ok in ((S * (S + 1) // 2, True), (3, False)):
+        eng = _engine(cfg, H, B, noise_mode=NOISE_BUFFER)
+        prior = eng.root_prepare(np.zeros((B, A), np.float32), np.ones((B, A)), np.full((B, A), 1 / 3), 0.25)
+        eng.reset(prior, np.zeros(B), np.stack([hashnet.hidden_of(int(c), hp) for c in codes]), np.zeros(B, np.int32),
+                  np.ones((B, A)))
+        eng.search_hash(4, 1, 1, noise=np.random.default_rng(0).random((B, rows, A)))
+        if ok:
+            eng.check()
+        else:
+            with pytest.raises(EngineError, match='noise buffer'):
+                eng.check()
+            eng.check()   # the flag is cleared by the report
         eng.close()
