@@ -375,11 +375,11 @@ def test_noise_key_follows_the_seed_of_each_search():
     rng = np.random.default_rng(5)
     A, S, H, B = 2, 40, 4, 256      # two actions with near-equal priors: ties are frequent
     cfg = make_config(False, A, S, 1, 0.997)
-    hp = hashnet.HashNetParams(A, H, 9, 0, 1)
+    hp = hashnet.HashNetParams(A, H, 30, 0, 1)   # logits of order 1e-7: the 1e-7 * u tie-break decides often
     codes, legal = _batch_inputs(A, B, rng)
     to_play = np.zeros(B, np.int32)
     dirichlet = np.full((B, A), 0.5)
-    logits = np.zeros((B, A), np.float32)
+    logits = np.stack([hashnet.logits_of(int(c), hp) for c in codes])
     eng = _engine(cfg, H, B, seed=3)
     seen = {}
     for seed in (3, 11):
@@ -390,7 +390,7 @@ def test_noise_key_follows_the_seed_of_each_search():
         prior = eng.root_prepare(logits, legal, dirichlet, 0.25)
         eng.reset(prior, [hashnet.value_of(int(c)) for c in codes], np.stack([hashnet.hidden_of(int(c), hp) for c in codes]),
                   to_play, legal, None, tree_id0=7)
-        eng.search_hash(9, 0, 1)
+        eng.search_hash(30, 0, 1)
         nv, _ = eng.stats()
         assert np.array_equal(nv.cpu().numpy(), ref.node_visits), seed
         seen[seed] = np.stack([eng.export_tree(b)['children_visits'][0] for b in range(32)])
