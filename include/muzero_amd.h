@@ -158,6 +158,21 @@ int mz_set_network_mfma(mz_ctx *ctx, const int32_t *steps_h, int32_t n_steps, co
 int mz_expand_backup_net(mz_ctx *ctx, int32_t select_next, const double *noise, int32_t noise_max_calls,
                          void *stream);
 
+/* mz_expand_backup_net with every byte of its staging (the per-level activations of the batched leaf evaluation,
+ * the leaves' logits / values / rewards handed to the expansion) in a fixed array inside the library's device image
+ * instead of buffers obtained from hipMalloc.  No counterpart in the reference: it exists for callers that cannot
+ * allocate device memory around the call - code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The call itself performs no hipMalloc / hipFree and uses no allocating library routine.
+ * Always evaluates level by level through that array (the path mz_expand_backup_net takes for batches below 4096
+ * trees), so its results equal mz_expand_backup_net's on that path bit for bit.
+ * Limit: rows * stride * 4 + B * (4 * n_actions + 16) bytes (rows = B rounded up to 32, stride = the activation floats
+ * per tree given to mz_set_network_mfma, each part rounded up to 256 bytes) must not exceed 16 MiB; larger batches
+ * are rejected with MZ_ERR_ARG.  Each GPU the library runs on holds the 16 MiB until the process ends.
+ * All calls on one GPU share the array, whichever context they come from: calls that overlap in time on one GPU
+ * (different streams or host threads) race; calls ordered on one stream do not. */
+int mz_expand_backup_net_static(mz_ctx *ctx, int32_t select_next, const double *noise, int32_t noise_max_calls,
+                                void *stream);
+
 /* Uploads the representation and prediction programs behind network.initial_inference
  * (network.py:86-103).  io_h int32[8] = {obs offset in the representation scratch, raw hidden offset in it,
  * hidden offset in the prediction scratch, policy logits offset, value logits offset, observation

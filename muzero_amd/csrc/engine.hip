@@ -102,6 +102,8 @@ static int dev_alloc(mz_ctx *c, T **p, size_t n)
     return MZ_OK;
 }
 
+static int scratch_for_device(int device, void **out);  // fixed device array of mz_expand_backup_net_static, below
+
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" mz_ctx *mz_create(const mz_config *cfg)
@@ -207,6 +209,8 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     c->rl = l0;
     d.discount = cfg->discount; d.c_visit = cfg->c_visit; d.c_scale = cfg->c_scale;
     d.seed = cfg->seed;
+    void *unused = nullptr;
+    if (scratch_for_device(cfg->device, &unused) != MZ_OK) { mz_destroy(c); return nullptr; }  // set-up, once per device
     return c;
 }
 
@@ -983,11 +987,19 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     return MZ_OK;
 }
 
-extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double *noise, int32_t noise_max_calls,
-                                    void *stream)
+// Staging of one batched leaf evaluation: activations of the per-level path ([rows][stride] floats, rows = the batch
+// rounded up to 32) and the network outputs k_expand_backup / k_backup_select consume.
+struct LeafStaging {
+    float *acts;
+    float *logits;   // [B][A]
+    double *value;   // [B]
+    double *reward;  // [B]
+};
+
+static int expand_backup_net_impl(mz_ctx *c, int32_t select_next, const double *noise, int32_t noise_max_calls,
+                                  void *stream, const LeafStaging &stg, bool force_by_level)
 {
-    int rc = check_ctx(c, "mz_expand_backup_net");
-    if (rc) return rc;
+    int rc = MZ_OK;
     if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no pending selection (call mz_select first)");
     if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_expand_backup_net: no network uploaded (call mz_set_network_mfma first)");
     int leaf = c->n_expanded + 1;
@@ -999,10 +1011,10 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
     // 32 trees per block while their activations fit in LDS, else 16; batches that would leave most CUs
     // without a tile (and networks whose tile does not fit at all) go level by level through global memory
     const int tm = (size_t)c->mnet.stride * 32 * 4 <= 160 * 1024 ? 32 : 16;
-    bool by_level = !c->mnet_tile_fits || (c->B + tm - 1) / tm < 128;
-    if (const char *e = getenv("MZ_NET_PATH")) by_level = !c->mnet_tile_fits || strcmp(e, "level") == 0;
+    bool by_level = force_by_level || !c->mnet_tile_fits || (c->B + tm - 1) / tm < 128;
+    if (const char *e = getenv("MZ_NET_PATH")) by_level = force_by_level || !c->mnet_tile_fits || strcmp(e, "level") == 0;
     if (by_level) {
-        float *acts = (float *)c->mnet_bufs[6];
+        float *acts = stg.acts;
         const int32_t *jobs = (const int32_t *)c->mnet_bufs[5];
         const unsigned tree_tiles = (unsigned)((c->B + 31) / 32);
         const size_t lds = (size_t)(c->mnet_max_k16 * 16 + 4) * 32 * 4;
@@ -1021,29 +1033,96 @@ extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double
         // a whole wave per tree when the supports or the hidden state are long
         if (c->mnet.io[9] > 64 || c->mnet.io[6] / c->mnet.io[10] > 64)
             hipLaunchKernelGGL(k_net_epilogue<64>, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, c->d, c->mnet, leaf,
-                               (const float *)acts, c->leaf_logits, c->leaf_value, c->leaf_reward);
+                               (const float *)acts, stg.logits, stg.value, stg.reward);
         else
             hipLaunchKernelGGL(k_net_epilogue<16>, dim3((c->B + 15) / 16), dim3(256), 0, (hipStream_t)stream, c->d, c->mnet, leaf,
-                               (const float *)acts, c->leaf_logits, c->leaf_value, c->leaf_reward);
+                               (const float *)acts, stg.logits, stg.value, stg.reward);
     } else {
         size_t lds = (size_t)c->mnet.stride * tm * 4;
         auto kern = tm == 32 ? k_net_step<32> : k_net_step<16>;
         // per launch, like the other kernels with large dynamic LDS: the attribute belongs to the current device
         HIPCHK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)lds));
         hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream, c->d,
-                           c->mnet, leaf, c->leaf_logits, c->leaf_value, c->leaf_reward);
+                           c->mnet, leaf, stg.logits, stg.value, stg.reward);
     }
     if ((rc = launch_status("mz_expand_backup_net"))) return rc;
     if (select_next) {
-        MZ_LAUNCH(c, k_backup_select, false, c->B, 0, stream, c->d, leaf, (const float *)c->leaf_logits,
-                  (const double *)c->leaf_value, (const double *)c->leaf_reward, noise, (int)noise_max_calls);
+        MZ_LAUNCH(c, k_backup_select, false, c->B, 0, stream, c->d, leaf, (const float *)stg.logits,
+                  (const double *)stg.value, (const double *)stg.reward, noise, (int)noise_max_calls);
     } else {
-        MZ_LAUNCH(c, k_expand_backup, false, c->B, 0, stream, c->d, leaf, (const float *)c->leaf_logits,
-                  (const double *)c->leaf_value, (const double *)c->leaf_reward, (const float *)nullptr);
+        MZ_LAUNCH(c, k_expand_backup, false, c->B, 0, stream, c->d, leaf, (const float *)stg.logits,
+                  (const double *)stg.value, (const double *)stg.reward, (const float *)nullptr);
     }
     c->n_expanded = leaf;
     c->selected = select_next ? 1 : 0;
     return launch_status("mz_expand_backup_net");
+}
+
+extern "C" int mz_expand_backup_net(mz_ctx *c, int32_t select_next, const double *noise, int32_t noise_max_calls,
+                                    void *stream)
+{
+    int rc = check_ctx(c, "mz_expand_backup_net");
+    if (rc) return rc;
+    const LeafStaging stg{(float *)c->mnet_bufs[6], c->leaf_logits, c->leaf_value, c->leaf_reward};
+    return expand_backup_net_impl(c, select_next, noise, noise_max_calls, stream, stg, false);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same step with its staging in a fixed array of the library's device image instead of buffers from hipMalloc.
+// `scratch` below is only a host-side handle of that array: its device address differs per GPU and is looked up
+// once per device (scratch_for_device); host code uses the looked-up pointer everywhere.
+#define MZ_STATIC_SCRATCH_BYTES (16u << 20)
+static __device__ __align__(256) unsigned char scratch[MZ_STATIC_SCRATCH_BYTES];
+
+#define MZ_MAX_DEVICES 64
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[MZ_MAX_DEVICES];
+
+// Device address of `scratch` on the current device (set by check_ctx / mz_create), resolved on first use.
+static int scratch_for_device(int device, void **out)
+{
+    if (device < 0 || device >= MZ_MAX_DEVICES) return fail(MZ_ERR_ARG, "static scratch: device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(MZ_ERR_HIP, std::string("static scratch: hipGetSymbolAddress failed: ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return MZ_OK;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int mz_expand_backup_net_static(mz_ctx *c, int32_t select_next, const double *noise, int32_t noise_max_calls,
+                                           void *stream)
+{
+    int rc = check_ctx(c, "mz_expand_backup_net_static");
+    if (rc) return rc;
+    if (!c->selected) return fail(MZ_ERR_STATE, "mz_expand_backup_net_static: no pending selection (call mz_select first)");
+    if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_expand_backup_net_static: no network uploaded (call mz_set_network_mfma first)");
+    const size_t rows = ((size_t)c->B + 31) / 32 * 32;
+    const size_t acts_bytes = align_up(rows * (size_t)c->mnet.stride * 4, 256);
+    const size_t logits_bytes = align_up((size_t)c->B * c->cfg.n_actions * 4, 256);
+    const size_t scalar_bytes = align_up((size_t)c->B * 8, 256);
+    const size_t need = acts_bytes + logits_bytes + 2 * scalar_bytes;
+    if (need > MZ_STATIC_SCRATCH_BYTES)
+        return fail(MZ_ERR_ARG, "mz_expand_backup_net_static: " + std::to_string(c->B) + " trees x " + std::to_string(c->mnet.stride) +
+                                    " activation floats need " + std::to_string(need) + " bytes of staging, the fixed scratch holds " +
+                                    std::to_string((size_t)MZ_STATIC_SCRATCH_BYTES) + "; use mz_expand_backup_net");
+    void *base = nullptr;
+    if ((rc = scratch_for_device(c->cfg.device, &base))) return rc;
+    unsigned char *p = reinterpret_cast<unsigned char *>(base);
+    const LeafStaging stg{reinterpret_cast<float *>(p), reinterpret_cast<float *>(p + acts_bytes),
+                          reinterpret_cast<double *>(p + acts_bytes + logits_bytes),
+                          reinterpret_cast<double *>(p + acts_bytes + logits_bytes + scalar_bytes)};
+    // The array keeps whatever the last call on this GPU left (another batch size, another network's layout): layers read
+    // their inputs in blocks of 16 floats, past the end of a tensor into padding that no layer writes, and that padding
+    // must be finite (its weights are zero).  Start every call from zeroed activations.
+    HIPCHK(hipMemsetAsync(stg.acts, 0, acts_bytes, (hipStream_t)stream));
+    return expand_backup_net_impl(c, select_next, noise, noise_max_calls, stream, stg, true);
 }
 
 extern "C" int mz_act_env_step(mz_ctx *c, const mz_env_state *env, double temperature, const double *u,

@@ -50,7 +50,7 @@ class MzEnvState(C.Structure):
 ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_set_seed', 'mz_check', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_act_env_step', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_expand_backup_net_static', 'mz_act_env_step', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
@@ -85,6 +85,7 @@ def lib():
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
         L.mz_set_network_mfma.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.c_int64, vp, i32, i32, vp]
         L.mz_expand_backup_net.argtypes = [vp, i32, vp, i32, vp]
+        L.mz_expand_backup_net_static.argtypes = [vp, i32, vp, i32, vp]
         L.mz_act_env_step.argtypes = [vp, C.POINTER(MzEnvState), f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mz_search_begin_net.argtypes = [vp, i32, vp, vp, vp, vp, f64, vp, u64, vp, vp, vp]
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
@@ -312,14 +313,16 @@ class SearchEngine:
                                          C.c_int64(pm.wfrag.size), vp(pm.bias), int(pm.bias.size), int(pm.stride),
                                          vp(io)))
 
-    def expand_backup_net(self, select_next: bool = False, noise=None):
+    def expand_backup_net(self, select_next: bool = False, noise=None, static_scratch: bool = False):
         """Leaf evaluation on the matrix cores + expansion + backup for the pending selection; with
-        `select_next` the next simulation's selection runs in the same launch."""
+        `select_next` the next simulation's selection runs in the same launch.  `static_scratch`: stage
+        through the library's fixed device array (mz_expand_backup_net_static; no allocation, 16 MiB limit)."""
         nz, max_calls = None, 0
         if noise is not None:
             nz = self._dev(noise, torch.float64)
             max_calls = nz.numel() // (self.B * self.A)
-        _check(lib().mz_expand_backup_net(self._ctx, C.c_int32(int(bool(select_next))), _ptr(nz), max_calls, _stream()))
+        fn = lib().mz_expand_backup_net_static if static_scratch else lib().mz_expand_backup_net
+        _check(fn(self._ctx, C.c_int32(int(bool(select_next))), _ptr(nz), max_calls, _stream()))
 
     def search_net(self, noise=None):
         """All simulations in one launch, leaves evaluated by the uploaded network."""
