@@ -18,6 +18,7 @@
 #include "dense_net.h"
 #include "net_mfma.h"      // matrix-core leaf evaluation; uses the epilogue helpers of dense_net.h
 #include "search_net.h"
+#include "search_cached.h"
 #include "search_reg.h"
 #include "env_step.h"
 #include "targets.h"
@@ -393,6 +394,28 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
     if (net_kind == MZ_NET_MFMA) {
         if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network_mfma first)");
         if (c->rl > 16) return fail(MZ_ERR_ARG, "mz_search_run: the matrix-core search serves at most 16 actions; use the step API");
+        // Gumbel trees whose record layout the decision-caching kernel is built for (9 actions: the 3x3 board games)
+        // walk down cached decisions and re-decide only the nodes a simulation changed (search_cached.h).
+        {
+            using GL = GumbelLayout<9>;
+            const Layout &L = c->d.L;
+            bool cached = c->cfg.gumbel && L.A == 9 && L.idx16 && L.rec == GL::rec && L.off_crew == GL::off_crew &&
+                          L.off_prior == GL::off_prior && L.off_cvis == GL::off_cvis && L.off_cidx == GL::off_cidx;
+            if (const char *e = getenv("MZ_SEARCH_CACHED")) cached = cached && atoi(e) != 0;
+            int ctm = 32;
+            if (const char *e = getenv("MZ_SEARCH_TM")) ctm = atoi(e) == 16 ? 16 : 32;
+            const size_t stat = (size_t)ctm * 16 * 8 + (size_t)ctm * 9 * 8 + (size_t)ctm * 24 + 64;
+            const size_t dyn = ((size_t)c->mnet.stride + L.N + L.S) * ctm * 4;
+            if (cached && dyn + stat <= 160 * 1024) {
+                auto kern = ctm == 32 ? k_search_gcache<32, 9> : k_search_gcache<16, 9>;
+                if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), dyn) != hipSuccess)
+                    return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
+                hipLaunchKernelGGL(kern, dim3((c->B + ctm - 1) / ctm), dim3(ctm * 16), dyn, (hipStream_t)stream, c->d, c->mnet,
+                                   c->n_expanded + 1, n_sims);
+                c->n_expanded += n_sims;
+                return launch_status("mz_search_run");
+            }
+        }
         // 32-tree tiles: 16-tree tiles (two or three blocks per CU) were measured no faster - each weight
         // fragment then serves one row block instead of two
         constexpr int tm = 32;

@@ -1,0 +1,346 @@
+// Gumbel search (sequential halving at the root, completed-Q policy improvement below it) with CACHED SELECTION
+// DECISIONS, leaves evaluated on the matrix cores; the whole simulation loop in one launch.
+//
+// Under the Gumbel rules the action chosen at a node (mcts/action_selection.py:73-118 with
+// mcts/qtransforms.py:25-77) is a pure function of that node's own record - priors, child visits, child values and
+// rewards, raw value; at the root also the tree's Gumbel noise, legality mask and visit schedule - and a record only
+// changes when the node lies on the path of a simulation (MCTS.backward, mcts/mcts.py:143-164, and the link written by
+// MCTS.expand, :116-141).  So instead of scoring every node of the path while walking down (a chain of dependent
+// record reads and float64 arithmetic per level, which is what bounds the level-by-level kernels), each simulation
+//   1. walks down a table of decisions kept in LDS (one 4-byte read per level, mcts/mcts.py:98-114),
+//   2. evaluates the leaf on the matrix cores (network.py:105-126),
+//   3. expands and backs up (tree_ops.h expand_backup), and
+//   4. re-decides exactly the nodes whose records changed - the path and the new leaf - all at once:
+//      one LANE per node, looping over the actions in registers (no cross-lane reductions, no idle action lanes),
+//      the (tree, level) pairs of the block's whole tile dealt evenly over its threads.
+// Every expression and operand order is the lane-group kernels' (tree_ops.h select_at and what it calls), with the
+// group reductions replaced by their serial equivalents, so trees come out bit for bit the same.
+// PUCT does not qualify: its score contains a fresh tie-break draw per selection call (mcts/action_selection.py:46).
+#pragma once
+#include <utility>
+#include "net_mfma.h"
+
+namespace mz {
+
+// Record layout of a Gumbel tree with A actions and 16-bit visit / index rows, as mz_create lays it out.
+template <int A>
+struct GumbelLayout {
+    static constexpr int ru(int x, int m) { return (x + m - 1) / m * m; }
+    static constexpr int off_cval = 32;
+    static constexpr int off_crew = off_cval + 8 * A;
+    static constexpr int off_prior = off_crew + 8 * A;
+    static constexpr int off_cvis = off_prior + ru(4 * A, 8);
+    static constexpr int off_cidx = off_cvis + ru(2 * A, 4);
+    static constexpr int rec = ru(off_cidx + 2 * A, 64);
+};
+
+// np.sum over A values in NumPy's order (numpy/_core/src/umath/loops_utils.h.src pairwise_sum below its block size):
+// sequential below 8 elements, else 8 strided accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the
+// tail added in order.  The serial twin of gsum_np (device_common.h).
+template <int A, typename T>
+__device__ __forceinline__ T np_sum_serial(const T (&x)[A])
+{
+    if constexpr (A < 8) {
+        T r = x[0];
+#pragma unroll
+        for (int i = 1; i < A; i++) r += x[i];
+        return r;
+    } else {
+        constexpr int lim = A - A % 8;
+        T r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = x[j];
+#pragma unroll
+        for (int i = 8; i < lim; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] += x[i + j];
+        }
+        T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = lim; i < A; i++) res += x[i];
+        return res;
+    }
+}
+
+// Compile-time loops and field extraction from a record held as 16-byte chunks in registers.
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>(), f); }
+
+template <int K, int NCH>
+__device__ __forceinline__ uint32_t rec_word(const uint4 (&ch)[NCH])
+{
+    const uint4 &v = ch[K / 4];
+    if constexpr (K % 4 == 0) return v.x;
+    else if constexpr (K % 4 == 1) return v.y;
+    else if constexpr (K % 4 == 2) return v.z;
+    else return v.w;
+}
+template <int OFF, int NCH>
+__device__ __forceinline__ double rec_f64(const uint4 (&ch)[NCH])
+{
+    return __builtin_bit_cast(double, ((unsigned long long)rec_word<OFF / 4 + 1>(ch) << 32) | (unsigned long long)rec_word<OFF / 4>(ch));
+}
+template <int OFF, int NCH>
+__device__ __forceinline__ int rec_i16(const uint4 (&ch)[NCH])
+{
+    return (int)(int16_t)(rec_word<OFF / 4>(ch) >> ((OFF & 3) * 8));
+}
+
+// A decision: the action the selection rule picks at a node and where it leads.
+//   word = (children_index[node, action] + 1) << 8 | action      (an unexpanded edge gives 0 in the upper bits)
+// One lane evaluates one node from its record in global memory.  `gum`: the tree's Gumbel noise [A] (root only),
+// `cv_row`: the tree's sequential-halving schedule (root only).
+template <int A>
+__device__ __forceinline__ int gumbel_decide(const Dev &d, const char *rec, bool is_root, unsigned long long legal,
+                                             const double *gum, const int32_t *cv_row)
+{
+    using GL = GumbelLayout<A>;
+    // the record as 16-byte chunks (it is 64-byte aligned); every field below sits at a compile-time position
+    constexpr int NCH = (GL::off_cidx + 2 * A + 15) / 16;
+    uint4 ch[NCH];
+    const uint4 *src = reinterpret_cast<const uint4 *>(rec);
+    static_for<NCH>([&](auto K) { ch[decltype(K)::value] = src[decltype(K)::value]; });
+    const double inf = __builtin_huge_val();
+    const double raw = rec_f64<24>(ch);
+    double q[A];
+    float pf[A];
+    int cv[A], ci[A];
+    int vsum = 0, vmax = -2147483647;
+    static_for<A>([&](auto I) {
+        constexpr int a = decltype(I)::value;
+        const double v = rec_f64<GL::off_cval + 8 * a>(ch), r = rec_f64<GL::off_crew + 8 * a>(ch);
+        q[a] = r + d.discount * v;                                     // Tree.qvalues, mcts/tree.py:55-58
+        pf[a] = __builtin_bit_cast(float, rec_word<(GL::off_prior + 4 * a) / 4>(ch));
+        cv[a] = rec_i16<GL::off_cvis + 2 * a>(ch);
+        ci[a] = rec_i16<GL::off_cidx + 2 * a>(ch);
+        vsum += cv[a];
+        vmax = cv[a] > vmax ? cv[a] : vmax;
+    });
+    // compute_mixed_value, mcts/qtransforms.py:51-77: only its entries at unvisited actions are used (:41), and there
+    // the reference divides the weighted q by 1.0
+    float e[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) e[a] = np_expf(pf[a]);
+    const float es = np_sum_serial<A, float>(e);
+    const float tiny = 1.17549435e-38f;
+    double pq[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        float p = __fdiv_rn(e[a], es);
+        p = p < tiny ? tiny : p;                                       // np.maximum(tiny, p): a NaN stays a NaN
+        pq[a] = cv[a] > 0 ? (double)p * q[a] : 0.0;
+    }
+    const double sum_pq = np_sum_serial<A, double>(pq);
+    const double wq = sum_pq / (double)1.0f;
+    const double mixed = (raw + (double)vsum * wq) / (double)(vsum + 1);
+    // qtransform_completed_by_mix_value, mcts/qtransforms.py:25-48
+    double comp[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) comp[a] = cv[a] > 0 ? q[a] : mixed;
+    double lo = comp[0], hi = comp[0];
+#pragma unroll
+    for (int a = 1; a < A; a++) {
+        const double y = comp[a];
+        lo = (y < lo || y != y) ? y : lo;                              // np.min / np.max: a NaN wins
+        hi = (y > hi || y != y) ? y : hi;
+    }
+    double den = hi - lo;
+    den = den < 1e-8 ? 1e-8 : den;                                     // np.maximum: a NaN stays a NaN
+    const double scale = (d.c_visit + (double)vmax) * d.c_scale;
+    double score[A];
+    if (is_root) {   // gumbel_muzero_root_action_selection, mcts/action_selection.py:73-96 with gumbel_score :147-157
+        const int considered = cv_row[vsum < d.L.S ? vsum : d.L.S - 1];
+        float lmax = pf[0];
+#pragma unroll
+        for (int a = 1; a < A; a++) lmax = pf[a] > lmax ? pf[a] : lmax;
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            const double cq = scale * ((comp[a] - lo) / den);
+            const float l = pf[a] - lmax;
+            double sc = (gum[a] + (double)l) + cq;
+            sc = sc < -1e9 ? -1e9 : sc;                                // np.maximum(-1e9, .) keeps a NaN
+            sc = sc + (cv[a] == considered ? 0.0 : -inf);
+            sc = sc != sc ? inf : sc;                                  // np.argmax: a NaN is the maximum
+            score[a] = ((legal >> a) & 1ull) ? sc : -inf;
+        }
+    } else {         // gumbel_muzero_interior_action_selection, mcts/action_selection.py:99-118
+        double e2[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            const double cq = scale * ((comp[a] - lo) / den);
+            e2[a] = exp((double)pf[a] + cq);
+        }
+        const double es2 = np_sum_serial<A, double>(e2);
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            double sc = e2[a] / es2 - (double)cv[a] / (double)(1 + vsum);
+            score[a] = sc != sc ? inf : sc;
+        }
+    }
+    int best = 0;
+    double bs = score[0];
+#pragma unroll
+    for (int a = 1; a < A; a++) {
+        if (score[a] > bs) { bs = score[a]; best = a; }                // first maximum
+    }
+    int child = 0;
+#pragma unroll
+    for (int a = 0; a < A; a++) child = a == best ? ci[a] : child;
+    return ((child + 1) << 8) | best;
+}
+
+template <int TM> struct Log2 { static constexpr int value = 1 + Log2<TM / 2>::value; };
+template <> struct Log2<1> { static constexpr int value = 0; };
+
+// Deals the items of the tile's trees (tree l has s_items[l] of them, numbered 0..s_items[l]-1) evenly over the block's
+// threads.  Every wave derives the same prefix sums from s_items in LDS and keeps them in its lanes 0..TM-1.
+struct PoolScan { int mine, incl, total; };
+
+template <int TM>
+__device__ __forceinline__ PoolScan pool_scan(const int *s_items, int lane)
+{
+    PoolScan p;
+    p.mine = lane < TM ? s_items[lane] : 0;
+    p.incl = p.mine;
+#pragma unroll
+    for (int off = 1; off < TM; off <<= 1) {
+        const int v = __shfl_up(p.incl, off, 64);
+        p.incl += lane >= off ? v : 0;
+    }
+    p.total = __shfl(p.incl, TM - 1, 64);
+    return p;
+}
+
+// The tree that owns item number `item` and the item's index inside that tree.  Call with every lane of the wave
+// active (lane reads); lanes whose item is beyond the total get a harmless answer.
+template <int TM>
+__device__ __forceinline__ void pool_locate(const PoolScan &p, int item, int *tree, int *j)
+{
+    int lo = 0, hi = TM - 1;   // smallest tree whose inclusive prefix exceeds `item`
+#pragma unroll
+    for (int step = 0; step < Log2<TM>::value; step++) {
+        const int mid = (lo + hi) >> 1;
+        const int v = __shfl(p.incl, mid, 64);
+        if (v > item) hi = mid; else lo = mid + 1;
+    }
+    const int tr = lo < TM ? lo : TM - 1;
+    *tree = tr;
+    *j = item - (__shfl(p.incl, tr, 64) - __shfl(p.mine, tr, 64));
+}
+
+// Dynamic LDS: activations [TM][stride] floats | decisions int32 [TM][N] | paths int32 [TM][S].
+template <int TM, int A>
+__global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, int first_leaf, int n_sims)
+{
+    extern __shared__ __align__(16) float act[];
+    __shared__ __align__(16) double s_bk[TM * 16];
+    __shared__ __align__(16) double s_gum[TM * A];
+    __shared__ unsigned long long s_legal[TM];
+    __shared__ int s_cvoff[TM], s_items[TM], s_depth[TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = tid / 16, a = tid % 16, t = blockIdx.x * TM + i;
+    const int H = net.io[6], N = d.L.N, S = d.L.S;
+    const bool live = t < d.B, on = a < A;
+    float *row = act + i * net.stride;
+    int32_t *dec_all = reinterpret_cast<int32_t *>(act + TM * net.stride);
+    int32_t *path_all = dec_all + TM * N;
+    double *bk = s_bk + i * 16;
+    tile_zero<TM>(act, net.stride, tid);
+    const int tt = live ? t : 0;  // groups past the end of the batch only keep the barriers company
+    TreeMem m = tree_mem(d, tt);
+    m.path = path_all + i * S;
+    int32_t *dec = dec_all + i * N;
+    float *hid = d.hidden + (long long)tt * N * H;
+    if (on) s_gum[i * A + a] = d.gumbel[(long long)tt * A + a];
+    if (a == 0) {
+        s_legal[i] = d.legal[tt];
+        s_cvoff[i] = d.m_considered[tt] * S;
+        s_items[i] = live ? first_leaf : 0;
+    }
+    long long visited = 0;
+    __syncthreads();
+    const char *tile_nodes = d.nodes + (long long)blockIdx.x * TM * d.L.tree_stride;
+    // every node that already exists (a fresh search: the roots)
+    {
+        const PoolScan ps = pool_scan<TM>(s_items, lane);
+        for (int base = 0; base < ps.total; base += TM * 16) {   // uniform trip count: pool_locate needs every lane
+            int tree, node;
+            pool_locate<TM>(ps, base + tid, &tree, &node);
+            if (base + tid < ps.total) {
+                const char *rec = tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec;
+                dec_all[tree * N + node] = gumbel_decide<A>(d, rec, node == 0, s_legal[tree], s_gum + tree * A,
+                                                            d.cv_table + s_cvoff[tree]);
+            }
+        }
+    }
+    __syncthreads();
+#ifdef MZ_STAMPS
+    long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_t = clock64();
+#endif
+    for (int s = 0; s < n_sims; s++) {
+        const int leaf = first_leaf + s;
+        int parent = 0, action = 0, ntp = 0, depth = 0;
+        if (live) {
+            // MCTS.simulate, mcts/mcts.py:98-114, over the decisions; all lanes of the group read the same words
+            int node = 0;
+            while (true) {
+                const int w = dec[node];
+                action = w & 0xff;
+                const int child = (w >> 8) - 1;
+                if (a == 0 && depth < S) m.path[depth] = (node << 6) | action;
+                depth++;
+                if (child < 0 || depth > S) break;  // depth bound: a malformed tree cannot spin forever
+                node = child;
+            }
+            parent = node;
+            ntp = d.players == 1 ? 0 : (depth & 1);  // starts at player 0, flips once per level (mcts/mcts.py:105,112)
+            visited += depth + 1;
+            tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
+        }
+        MZ_MSTAMP(st_a)
+        __syncthreads();
+        MZ_MSTAMP(st_b)
+        tile_run_levels<TM>(net, act, wave, lane);
+        MZ_MSTAMP(st_c)
+        if (live) {
+            double value, reward;
+            tile_epilogue(net, row, a, hid + (long long)leaf * H, &value, &reward);
+            const float lg = on ? row[net.io[4] + a] : 0.0f;
+            expand_backup<16, true>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
+            if (a == 0) { s_items[i] = depth + 1; s_depth[i] = depth; }
+        }
+        __threadfence_block();   // the records the backup wrote are read by other lanes of the block below
+        __syncthreads();
+        MZ_MSTAMP(st_d)
+        // the nodes whose records changed: levels 0..depth-1 of each tree's path, and its new leaf
+        {
+            const PoolScan ps = pool_scan<TM>(s_items, lane);
+            for (int base = 0; base < ps.total; base += TM * 16) {
+                int tree, j;
+                pool_locate<TM>(ps, base + tid, &tree, &j);
+                if (base + tid < ps.total) {
+                    const int node = j < s_depth[tree] ? (path_all[tree * S + j] >> 6) : leaf;
+                    const char *rec = tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec;
+                    dec_all[tree * N + node] = gumbel_decide<A>(d, rec, node == 0, s_legal[tree], s_gum + tree * A,
+                                                                d.cv_table + s_cvoff[tree]);
+                }
+            }
+        }
+        __syncthreads();
+        MZ_MSTAMP(st_e)
+    }
+#ifdef MZ_STAMPS
+    if (live && a == 0) {  // diagnostic build only: [walk+stage, barrier wait, network, epilogue+backup, decisions] cycles
+        long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
+        o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = st_d; o[4] = st_e;
+    }
+#endif
+    if (live && a == 0) d.visit_total[t] += visited;
+}
+
+}  // namespace mz

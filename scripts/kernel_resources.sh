@@ -1,0 +1,7 @@
+#!/bin/bash
+# Registers, spills, LDS and occupancy of every kernel as the compiler reports them (device code only, nothing is linked).
+# usage: scripts/kernel_resources.sh [name filter] > report
+cd "$(dirname "$0")/.."
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 --offload-device-only -c \
+    -Rpass-analysis=kernel-resource-usage muzero_amd/csrc/engine.hip -o /tmp/mz_engine_dev.o 2>&1 |
+    awk -v pat="${1:-.}" '/Function Name:/ {keep = ($0 ~ pat)} keep && /remark:/ {sub(/^.*remark: [^ ]* /, ""); print}'

@@ -1,0 +1,95 @@
+"""GPU: the Gumbel whole-search kernel that walks cached decisions (csrc/search_cached.h) against the kernel that
+scores every node on the way down (k_search_mfma).  Both evaluate leaves with the same matrix-core code, so every
+tree field must agree bit for bit - fresh searches, searches resumed after stepped simulations, illegal root
+actions, either player to move, ragged batches, both tile sizes."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_config
+from test_network_lowering import load_net, net_config
+from muzero_amd.network import MuZeroNetwork
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(monkeypatch, cached, tm, cfg, net, pm_io, logits, hidden, value, legal, tp, g, stepped, B):
+    from muzero_amd.engine import SearchEngine
+    monkeypatch.setenv('MZ_SEARCH_CACHED', '1' if cached else '0')
+    monkeypatch.setenv('MZ_SEARCH_TM', str(tm))
+    eng = SearchEngine(cfg, net.H, B, seed=2)
+    eng.set_network_mfma(*pm_io)
+    prior = eng.root_prepare(logits, legal, None, 0.0)
+    eng.reset(prior, value, hidden, tp, legal, g)
+    if stepped:
+        eng.select(want_hidden=False)
+        for i in range(stepped):
+            eng.expand_backup_net(select_next=i + 1 < stepped)
+    eng.search_mfma()
+    action, rv, probs, q = eng.to_act(0.0)
+    nv, _ = eng.stats()
+    out = dict(action=action.cpu().numpy().copy(), value=rv.cpu().numpy().copy(), probs=probs.cpu().numpy().copy(),
+               q=q.cpu().numpy().copy(), nv=nv.cpu().numpy().copy(),
+               trees=[eng.export_tree(b) for b in sorted({x for x in (0, 1, B // 3, B // 2, B - 2, B - 1) if 0 <= x < B})])
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize('S,B,stepped', [(100, 70, 0), (40, 33, 5), (7, 1, 0), (25, 129, 24)])
+def test_cached_decisions_give_the_same_trees(S, B, stepped, monkeypatch):
+    from muzero_amd.packing import pack_network_mfma
+    z, net = load_net('resnet_tictactoe')
+    net = MuZeroNetwork(net_config('resnet_tictactoe'), net.state_dict()).to('cuda')
+    pm_io = pack_network_mfma(net)
+    rng = np.random.default_rng(S + B)
+    cfg = make_config(True, 9, S, 2, 1)
+    obs = z['obs'][rng.integers(0, len(z['obs']), size=B)].astype(np.float32)
+    with torch.no_grad():
+        logits, hidden, value = net.initial_flat(torch.as_tensor(obs.reshape(B, -1), device='cuda'))
+    legal = np.ones((B, 9))
+    for b in range(0, B, 3):
+        legal[b, rng.choice(9, size=rng.integers(1, 8), replace=False)] = 0
+    tp = rng.integers(0, 2, size=B).astype(np.int32)
+    g = rng.gumbel(size=(B, 9))
+    want = _run(monkeypatch, False, 32, cfg, net, pm_io, logits, hidden, value, legal, tp, g, stepped, B)
+    assert want['nv'].sum() > B * S            # the reference kernel really searched
+    for tm in (32, 16):
+        got = _run(monkeypatch, True, tm, cfg, net, pm_io, logits, hidden, value, legal, tp, g, stepped, B)
+        for k in ('action', 'value', 'probs', 'q', 'nv'):
+            np.testing.assert_array_equal(want[k], got[k], err_msg=f'{k} tm={tm}')
+        for tw, tg in zip(want['trees'], got['trees']):
+            for k in tw:
+                np.testing.assert_array_equal(tw[k], tg[k], err_msg=f'{k} tm={tm}')
+
+
+def test_cached_decisions_on_degenerate_priors(monkeypatch):
+    """Roots whose float32 prior softmax underflows entirely (the reference scores NaN everywhere and plays the first
+    legal action), and chains: a policy head that always prefers one action."""
+    from muzero_amd.packing import pack_network_mfma
+    z, net0 = load_net('resnet_tictactoe')
+    sd = {k: v.clone() for k, v in net0.state_dict().items()}
+    key = [k for k in sd if 'policy' in k and k.endswith('bias')][-1]
+    sd[key][4] += 40.0
+    net = MuZeroNetwork(net_config('resnet_tictactoe'), sd).to('cuda')
+    pm_io = pack_network_mfma(net)
+    rng = np.random.default_rng(1)
+    B, S = 48, 60
+    cfg = make_config(True, 9, S, 2, 1)
+    obs = z['obs'][rng.integers(0, len(z['obs']), size=B)].astype(np.float32)
+    with torch.no_grad():
+        logits, hidden, value = net.initial_flat(torch.as_tensor(obs.reshape(B, -1), device='cuda'))
+    logits = logits.clone()
+    logits[::4] -= 200.0                         # exp underflows for every action of these roots
+    legal = np.ones((B, 9))
+    legal[1::4, :3] = 0
+    tp = np.zeros(B, np.int32)
+    g = rng.gumbel(size=(B, 9))
+    want = _run(monkeypatch, False, 32, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
+    got = _run(monkeypatch, True, 32, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
+    assert want['nv'].max() > S * 10             # chains: leaves far below the root
+    for k in ('action', 'value', 'nv'):
+        np.testing.assert_array_equal(want[k], got[k], err_msg=k)
+    np.testing.assert_array_equal(np.isnan(want['probs']), np.isnan(got['probs']))
+    for tw, tg in zip(want['trees'], got['trees']):
+        for k in tw:
+            np.testing.assert_array_equal(tw[k], tg[k], err_msg=k)
