@@ -55,7 +55,7 @@ struct mz_ctx {
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
     MfmaNet mnet;       // MFMA-layout network (mz_set_network_mfma)
-    void *mnet_bufs[7];  // steps, tiles, level_start, wfrag, bias, per-level job table, global activations
+    void *mnet_bufs[9];  // steps, tiles, level_start, wfrag, bias, per-level job table, global activations, ctinfo, kidx
     int mnet_max_k16;                  // widest layer input in blocks of 16 floats
     std::vector<int> mnet_level_job0;  // first block of each level in the job table (+ total at the end)
     bool mnet_tile_fits;               // a 16-tree activation tile fits in LDS (tile-resident kernels usable)
@@ -942,15 +942,18 @@ extern "C" int mz_debug_read_path(mz_ctx *c, void *out_h, size_t n_bytes)
 extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_steps, const int32_t *tiles_h,
                                    int32_t n_tiles, const int32_t *level_start_h, int32_t n_levels,
                                    const float *wfrag_h, int64_t n_w, const float *bias_h, int32_t n_b,
-                                   int32_t stride, const int32_t *io_h)
+                                   const int32_t *ctinfo_h, int32_t n_jobs, const int32_t *kidx_h, int32_t n_kidx,
+                                   int32_t stride, int32_t plane_major, const int32_t *io_h)
 {
     int rc = check_ctx(c, "mz_set_network_mfma");
     if (rc) return rc;
-    if (!steps_h || !tiles_h || !level_start_h || !wfrag_h || !bias_h || !io_h || n_steps < 1 || n_tiles < 1 || n_levels < 1)
+    if (!steps_h || !tiles_h || !level_start_h || !wfrag_h || !bias_h || !ctinfo_h || !kidx_h || !io_h || n_steps < 1 ||
+        n_tiles < 1 || n_levels < 1 || n_jobs < 1 || n_kidx < 1)
         return fail(MZ_ERR_ARG, "mz_set_network_mfma: null/empty program");
     if (io_h[6] != c->cfg.hidden_size || io_h[7] != c->cfg.n_actions)
         return fail(MZ_ERR_ARG, "mz_set_network_mfma: network hidden size / action count differ from the context's");
     if (io_h[10] < 1 || io_h[6] % io_h[10]) return fail(MZ_ERR_ARG, "mz_set_network_mfma: hidden size not divisible by normalisation groups");
+    if (plane_major && io_h[10] < 8) return fail(MZ_ERR_ARG, "mz_set_network_mfma: plane-major storage needs at least 8 normalisation groups (channels)");
     if (stride % 8 != 4) return fail(MZ_ERR_ARG, "mz_set_network_mfma: stride must be 4 times an odd number");
     if (stride > (1 << 20)) return fail(MZ_ERR_ARG, "mz_set_network_mfma: unreasonable activation row");
     if (level_start_h[n_levels] != n_tiles) return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent tile table");
@@ -958,8 +961,16 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
         const int32_t *st = steps_h + 12 * s;
         int k16 = st[2], nct = st[9];
         if (st[3] < 0 || st[3] + k16 * 16 > stride || st[4] < 0 || st[4] + nct * 16 > stride || st[5] + nct * 16 > stride ||
-            st[7] < 0 || (int64_t)st[7] + (int64_t)nct * k16 * 256 > n_w || st[8] < 0 || st[8] + nct * 16 > n_b)
+            st[8] < 0 || st[8] + nct * 16 > n_b || st[10] < 0 || st[10] + nct > n_jobs)
             return fail(MZ_ERR_ARG, "mz_set_network_mfma: a step addresses outside its buffers");
+        for (int ct = 0; ct < nct; ct++) {
+            const int32_t *job = ctinfo_h + 3 * (st[10] + ct);
+            if (job[0] < 0 || job[2] < 0 || (int64_t)job[0] + (int64_t)job[2] * 256 > n_w || job[1] < 0 || job[1] + job[2] > n_kidx)
+                return fail(MZ_ERR_ARG, "mz_set_network_mfma: a column tile addresses outside the weight blocks");
+            for (int i = 0; i < job[2]; i++)
+                if (kidx_h[job[1] + i] < 0 || kidx_h[job[1] + i] >= k16)
+                    return fail(MZ_ERR_ARG, "mz_set_network_mfma: a weight block lies outside its layer's inputs");
+        }
     }
     for (int i = 0; i < n_tiles; i++)
         if (tiles_h[2 * i] < 0 || tiles_h[2 * i] >= n_steps || tiles_h[2 * i + 1] < 0 ||
@@ -1001,10 +1012,16 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
         HIPCHK(hipMalloc(&c->mnet_bufs[i], n[i] * 4));
         HIPCHK(hipMemcpy(c->mnet_bufs[i], src[i], n[i] * 4, hipMemcpyHostToDevice));
     }
+    HIPCHK(hipMalloc(&c->mnet_bufs[7], (size_t)n_jobs * 12));
+    HIPCHK(hipMemcpy(c->mnet_bufs[7], ctinfo_h, (size_t)n_jobs * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->mnet_bufs[8], (size_t)n_kidx * 4));
+    HIPCHK(hipMemcpy(c->mnet_bufs[8], kidx_h, (size_t)n_kidx * 4, hipMemcpyHostToDevice));
     MfmaNet &m = c->mnet;
     m.steps = (const int32_t *)c->mnet_bufs[0]; m.tiles = (const int32_t *)c->mnet_bufs[1];
     m.level_start = (const int32_t *)c->mnet_bufs[2]; m.wfrag = (const float *)c->mnet_bufs[3];
     m.bias = (const float *)c->mnet_bufs[4];
+    m.ctinfo = (const int32_t *)c->mnet_bufs[7]; m.kidx = (const int32_t *)c->mnet_bufs[8];
+    m.plane_major = plane_major ? 1 : 0;
     m.n_steps = n_steps; m.n_levels = n_levels; m.stride = stride;
     memcpy(m.io, io_h, sizeof m.io);
     return MZ_OK;

@@ -4,7 +4,8 @@
 // muzero_amd/packing.py) for a tile of TM = 32 trees.  The tile's activations live in LDS
 // ([32][stride] floats, stride = 4 x odd so the 16 rows of an operand read start in 16 different bank groups); weights
 // stream from L2 in v_mfma_f32_16x16x4_f32 operand order, one 16-byte load per lane per four k-steps, and every loaded fragment is used for both 16-row halves
-// of the tile (two independent accumulators, which also covers the MFMA's dependent latency).
+// of the tile (two independent accumulators, which also covers the MFMA's dependent latency).  Weights are block-sparse:
+// a (step, column tile) job lists the 16-input blocks that hold a non-zero weight and only those are loaded and multiplied.
 // Within a level the (step, column tile) jobs are dealt round-robin to the four waves; levels are
 // separated by a workgroup barrier.  float32 in, float32 accumulate: a k-ordered fma chain per
 // output, same rounding class as the reference's float32 network.
@@ -22,7 +23,10 @@ struct MfmaNet {
     const int32_t *level_start;  // [n_levels + 1]
     const float *wfrag;
     const float *bias;
+    const int32_t *ctinfo;       // per (step, column tile) job: weight offset (floats), first entry in kidx, number of blocks
+    const int32_t *kidx;         // 16-input block indices of the jobs' stored blocks
     int n_steps, n_levels, stride;
+    int plane_major;             // the hidden state inside the activation row is [cell][channel] (channels = io[10])
     int io[12];  // in_hidden, in_action, out_next, out_reward, out_policy, out_value, H, A, action_size, support, norm_groups, obs
 };
 
@@ -50,23 +54,27 @@ template <int HALVES>
 __device__ __forceinline__ void mfma_tile(const MfmaNet &net, const float *in, int in_stride, int in_off, float *out,
                                           int out_stride, const int32_t *st, int ct, int half, int lane)
 {
-    const int N = st[1], k16n = st[2], out_off = st[4], skip_off = st[5], actf = st[6];
-    const float4 *wp = reinterpret_cast<const float4 *>(net.wfrag + st[7]) + (long long)ct * k16n * 64 + lane;
+    const int N = st[1], out_off = st[4], skip_off = st[5], actf = st[6];
+    const int32_t *job = net.ctinfo + 3 * (st[10] + ct);
+    const int nkb = job[2];
+    const float4 *wp = reinterpret_cast<const float4 *>(net.wfrag + job[0]) + lane;
+    const int32_t *kx = net.kidx + job[1];
     const int row0 = HALVES == 2 ? 0 : half * 16;
     const float *a0 = in + (row0 + (lane & 15)) * in_stride + in_off + (lane >> 4) * 4;
     const float *a1 = a0 + 16 * in_stride;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < k16n; k0 += MZ_WPF) {
+    for (int k0 = 0; k0 < nkb; k0 += MZ_WPF) {
         float4 w[MZ_WPF];
+        int kb[MZ_WPF];
 #pragma unroll
         for (int i = 0; i < MZ_WPF; i++)
-            if (k0 + i < k16n) w[i] = wp[(k0 + i) * 64];
+            if (k0 + i < nkb) { w[i] = wp[(k0 + i) * 64]; kb[i] = kx[k0 + i]; }
 #pragma unroll
         for (int i = 0; i < MZ_WPF; i++) {
-            if (k0 + i < k16n) {
-                float4 x0 = *reinterpret_cast<const float4 *>(a0 + (k0 + i) * 16);
+            if (k0 + i < nkb) {
+                float4 x0 = *reinterpret_cast<const float4 *>(a0 + kb[i] * 16);
                 float4 x1 = {0, 0, 0, 0};
-                if constexpr (HALVES == 2) x1 = *reinterpret_cast<const float4 *>(a1 + (k0 + i) * 16);
+                if constexpr (HALVES == 2) x1 = *reinterpret_cast<const float4 *>(a1 + kb[i] * 16);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, w[i].x, acc0, 0, 0, 0);
                 if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w[i].x, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, w[i].y, acc0, 0, 0, 0);
@@ -113,11 +121,15 @@ __device__ __forceinline__ void tile_zero(float *act, int stride, int tid)
     for (int i = tid; i < TM * stride / 4; i += TM * 16) a4[i] = z;
 }
 
-// inputs of one tree: hidden state of its selected PARENT and the encoded action (mcts/mcts.py:240-243)
+// inputs of one tree: hidden state of its selected PARENT and the encoded action (mcts/mcts.py:240-243).  Stored hidden
+// states are [channel][cell]; a plane-major network wants [cell][channel] in its activation row.
 __device__ __forceinline__ void tile_stage_inputs(const MfmaNet &net, float *row, const float *ph, int action, int a)
 {
     const int H = net.io[6], asz = net.io[8];
-    if ((H & 3) == 0) {
+    if (net.plane_major) {
+        const int C = net.io[10], P = H / C;
+        for (int j = a; j < H; j += 16) row[net.io[0] + (j % P) * C + j / P] = ph[j];
+    } else if ((H & 3) == 0) {
         const float4 *p4 = reinterpret_cast<const float4 *>(ph);
         float4 *r4 = reinterpret_cast<float4 *>(row + net.io[0]);
         for (int j = a; j < H / 4; j += 16) r4[j] = p4[j];
@@ -129,14 +141,15 @@ __device__ __forceinline__ void tile_stage_inputs(const MfmaNet &net, float *row
 
 // all levels of the program for a tile of TM (32 or 16) trees; ends with a workgroup barrier
 template <int TM>
-__device__ __forceinline__ void tile_run_levels(const MfmaNet &net, float *act, int wave, int lane)
+__device__ __forceinline__ void tile_run_levels(const MfmaNet &net, float *act, int wave_v, int lane)
 {
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);  // wave-uniform: job tables are then read with scalar loads
     for (int l = 0; l < net.n_levels; l++) {
         constexpr int NW = TM * 16 / 64;
         const int first = net.level_start[l], n_tiles = net.level_start[l + 1] - first;
         if constexpr (TM == 16) {  // one 16-row block per column tile
             for (int ti = wave; ti < n_tiles; ti += NW) {
-                int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
+                const int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
                 mfma_tile<1>(net, act, net.stride, net.steps[12 * s + 3], act, net.stride, net.steps + 12 * s, ct, 0, lane);
             }
             __syncthreads();
@@ -170,12 +183,13 @@ __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *r
     const int H = net.io[6], sup = net.io[9], ngroups = net.io[10];
     const int per = H / ngroups;
     if (ngroups >= 8) {  // many small groups (board planes): one lane per group
+        const int sj = net.plane_major ? ngroups : 1, sg = net.plane_major ? 1 : per;  // element (g, j) at g * sg + j * sj
         for (int g = a; g < ngroups; g += LANES) {
-            const float *raw = row + net.io[2] + g * per;
+            const float *raw = row + net.io[2] + g * sg;
             float mn = raw[0], mx = raw[0];
-            for (int j = 1; j < per; j++) { float v = raw[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+            for (int j = 1; j < per; j++) { float v = raw[j * sj]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
             float den = (mx - mn) + 1e-5f;
-            for (int j = 0; j < per; j++) hidden_dst[g * per + j] = (raw[j] - mn) / den;
+            for (int j = 0; j < per; j++) hidden_dst[g * per + j] = (raw[j * sj] - mn) / den;
         }
     } else {
         minmax_to<LANES>(row + net.io[2], H, ngroups, a, hidden_dst, nullptr);
@@ -244,7 +258,10 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level(Dev d, MfmaNet 
         for (int j = part; j < KK; j += PT) {
             int e = j + rel;
             float v = 0.0f;
-            if (live) v = e < H ? ph[e] : ((e - H == action && e < H + asz) ? 1.0f : 0.0f);
+            if (live) {
+                if (e < H) v = net.plane_major ? ph[(e % net.io[10]) * (H / net.io[10]) + e / net.io[10]] : ph[e];
+                else v = (e - H == action && e < H + asz) ? 1.0f : 0.0f;
+            }
             dst[j] = v;
             // later levels may read the inputs too (residual skips): keep them in `acts` as well (the
             // blocks of this level that share a tree tile write the same values)

@@ -141,24 +141,36 @@ def pack_network(net) -> PackedNetwork:
 # ---------------------------------------------------------------------- MFMA layout
 # For programs too large for LDS-resident weights (board ResNets, wide MLPs) a tile of trees keeps
 # its ACTIVATIONS in LDS and streams the weights, pre-swizzled into v_mfma_f32_16x16x4_f32 operand
-# order, from L2.  Per step (one dense layer) and 16-column tile `ct` the weights are stored as
-#   Wfrag[ct][k16][lane 0..63][4]   with   col = ct*16 + (lane & 15),   k = k16*16 + (lane >> 4)*4 + j
+# order, from L2.  A step (one dense layer) is cut into 16-column tiles `ct` and 16-input blocks `k16`;
+# only blocks that hold a non-zero weight are stored and multiplied (BLOCK-SPARSE): the dense matrix of
+# a 3x3 convolution on a small board is 40 % zero blocks once its tensors are laid out position-major
+# ([cell][channel], see `plane_major` below), because a cell only sees its neighbours.  Per (step, ct) job:
+#   ctinfo[job] = (weight offset in floats, first entry in kidx, number of blocks)
+#   kidx[...]   = the k16 indices of the job's blocks, ascending
+#   Wfrag[block][lane 0..63][4]   with   col = ct*16 + (lane & 15),   k = k16*16 + (lane >> 4)*4 + j
 # so one 16-byte load per lane feeds four MFMA k-steps (a wave reads 1 KiB contiguously) and the
 # matching activations of a lane are four consecutive floats (one 16-byte LDS read).
 # int32 step table, 12 ints per step:
-#   level, N, K16 (= ceil(K/16)), in_off, out_off, skip_off (-1), act, w_off (floats), b_off (floats), n_col_tiles, 0, 0
-# int32 tile table: (step, ct) pairs ordered by level; level_start[l] .. level_start[l+1] index it.
+#   level, N, K16 (= ceil(K/16)), in_off, out_off, skip_off (-1), act, w_off (floats, first job), b_off (floats),
+#   n_col_tiles, first job in ctinfo, 0
+# int32 tile table: (step, ct) pairs ordered by level, inside a level by falling block count in serpentine order
+# over 8 waves (the waves of a block take the entries round-robin); level_start[l] .. level_start[l+1] index it.
 @dataclass
 class PackedMfma:
     steps: np.ndarray        # int32 [n_steps * 12]
     tiles: np.ndarray        # int32 [n_tiles * 2]
     level_start: np.ndarray  # int32 [n_levels + 1]
-    wfrag: np.ndarray        # float32
+    wfrag: np.ndarray        # float32, the stored blocks
     bias: np.ndarray         # float32 (each step padded to 16 columns)
     stride: int              # activation floats per tree (4 x an odd number: conflict-free 16-byte operand reads)
     slots: Dict[str, int]
     macs: int                # unpadded multiply-accumulates per tree
-    padded_macs: int         # what the MFMA tiles actually compute per tree
+    padded_macs: int         # what the MFMA tiles actually compute per tree (stored blocks x 256)
+    ctinfo: np.ndarray = None   # int32 [n_jobs * 3]
+    kidx: np.ndarray = None     # int32 [n_blocks]
+    plane_major: int = 0        # 1: the hidden state inside the activation row is [cell][channel] (channels = the
+                                # normalisation groups), not the [channel][cell] order of the stored hidden states
+    dense_macs: int = 0         # what a dense evaluation of the same tiles would compute
 
 
 def _assign_slots(steps, inputs, aliases, keep):
@@ -209,40 +221,65 @@ def _assign_slots(steps, inputs, aliases, keep):
 
 
 def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = None,
-              keep: Sequence[str] = ()) -> PackedMfma:
-    """keep: tensors that must survive to the end of the program (what the epilogue reads)."""
+              keep: Sequence[str] = (), perms: Dict[str, np.ndarray] = None) -> PackedMfma:
+    """keep: tensors that must survive to the end of the program (what the epilogue reads).
+    perms: tensor name -> permutation p (position i of the stored tensor holds element p[i] of the program's
+    tensor); tensors not named keep their order."""
     aliases = aliases or {}
+    perms = perms or {}
     slots, level_of, end = _assign_slots(steps, inputs, aliases, keep)
     sizes: Dict[str, int] = {n: int(sz) for n, sz in inputs.items()}
     for name, (base, o, size) in aliases.items():
         sizes[name] = int(size)
-    table, wblobs, bblobs = [], [], []
-    w_off = b_off = macs = padded = 0
+    table, wblobs, bblobs, ctinfo, kidx = [], [], [], [], []
+    w_off = b_off = macs = padded = dense = 0
     per_level: Dict[int, list] = {}
     for si, s in enumerate(steps):
         N, K = (int(x) for x in s.W.shape)
         if sizes[s.inp] != K:
             raise ValueError(f'step {s.out}: input {s.inp} has {sizes[s.inp]} floats, weight expects {K}')
+        if s.skip and not np.array_equal(perms.get(s.skip, np.arange(N)), perms.get(s.out, np.arange(N))):
+            raise ValueError(f'step {s.out}: the residual input must be stored in the same order as the output')
         lv = level_of[s.out]
         sizes[s.out] = N
         k16, nct = (K + 15) // 16, (N + 15) // 16
+        W = s.W.detach().cpu().numpy()
+        b = s.b.detach().cpu().numpy()
+        if s.out in perms:
+            W, b = W[perms[s.out]], b[perms[s.out]]
+        if s.inp in perms:
+            W = W[:, perms[s.inp]]
         Wp = np.zeros((nct * 16, k16 * 16), np.float32)
-        Wp[:N, :K] = s.W.detach().cpu().numpy()
+        Wp[:N, :K] = W
         # [ct][col16][k16][kk][j] -> [ct][k16][kk*16 + col16][j]
-        frag = Wp.reshape(nct, 16, k16, 4, 4).transpose(0, 2, 3, 1, 4).reshape(-1)
+        frag = Wp.reshape(nct, 16, k16, 4, 4).transpose(0, 2, 3, 1, 4).reshape(nct, k16, 256)
         bp = np.zeros(nct * 16, np.float32)
-        bp[:N] = s.b.detach().cpu().numpy()
+        bp[:N] = b
         table += [lv - 1, N, k16, slots[s.inp], slots[s.out], slots[s.skip] if s.skip else -1, ACT[s.act], w_off, b_off,
-                  nct, 0, 0]
-        per_level.setdefault(lv - 1, []).extend((si, ct) for ct in range(nct))
-        wblobs.append(frag); bblobs.append(bp)
-        w_off += frag.size; b_off += bp.size
-        macs += N * K; padded += nct * 16 * k16 * 16
+                  nct, len(ctinfo) // 3, 0]
+        for ct in range(nct):
+            live = [kb for kb in range(k16) if np.any(frag[ct, kb] != 0.0)]
+            ctinfo += [w_off, len(kidx), len(live)]
+            kidx += live
+            for kb in live:
+                wblobs.append(frag[ct, kb])
+            w_off += 256 * len(live)
+            padded += 256 * len(live)
+            per_level.setdefault(lv - 1, []).append((len(live), si, ct))
+        bblobs.append(bp)
+        b_off += bp.size
+        macs += N * K
+        dense += nct * 16 * k16 * 16
     n_levels = max(per_level) + 1 if per_level else 0
     tiles, level_start = [], [0]
     for lv in range(n_levels):
-        for (si, ct) in per_level.get(lv, []):
-            tiles += [si, ct]
+        jobs = sorted(per_level.get(lv, []), key=lambda x: (-x[0], x[1], x[2]))
+        for r in range(0, len(jobs), 8):       # serpentine: every second round of 8 in rising order
+            chunk = jobs[r:r + 8]
+            if (r // 8) % 2:
+                chunk = chunk[::-1]
+            for (_, si, ct) in chunk:
+                tiles += [si, ct]
         level_start.append(len(tiles) // 2)
     # an input is read in blocks of 16 floats, i.e. up to 15 floats past its own end, where the weights
     # are zero but the values must exist: the row covers the furthest such read
@@ -251,16 +288,41 @@ def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple]
     stride = (stride + 3) // 4 * 4
     if stride % 8 == 0:
         stride += 4                      # 4 x odd: rows start 4 x (odd multiple) banks apart
+    wfrag = np.concatenate(wblobs) if wblobs else np.zeros(256, np.float32)
     return PackedMfma(np.asarray(table, np.int32), np.asarray(tiles, np.int32), np.asarray(level_start, np.int32),
-                      np.concatenate(wblobs), np.concatenate(bblobs), int(stride), slots, macs, padded)
+                      np.ascontiguousarray(wfrag, np.float32), np.concatenate(bblobs), int(stride), slots, macs, padded,
+                      np.asarray(ctinfo, np.int32), np.asarray(kidx if kidx else [0], np.int32), 0, dense)
 
 
-def pack_network_mfma(net):
+def plane_major_permutation(channels: int, cells: int) -> np.ndarray:
+    """p with p[cell * channels + c] = c * cells + cell: [channel][cell] tensors stored [cell][channel]."""
+    return np.arange(channels * cells).reshape(channels, cells).T.reshape(-1).copy()
+
+
+def pack_network_mfma(net, plane_major=None):
     """Recurrent program (dynamics + prediction of the parent state) of a lowered network in MFMA
-    layout, with the io vector of PackedNetwork.io()."""
+    layout, with the io vector of PackedNetwork.io().
+    Board networks whose channel count is a multiple of 16 store every [channel][cell] feature map of the
+    program cell-major, which turns the zero pattern of their lowered convolutions into whole zero blocks
+    (`plane_major`, default: on when it applies); stored hidden states keep the reference's order, the kernels
+    translate when they load the parent's state and store the new one."""
     H, asz = net.H, net.action_size
-    pm = pack_mfma(list(net.dyn.steps) + list(net.pred.steps), {'xa': H + asz}, {'hidden': ('xa', 0, H)},
-                   keep=('next_raw', 'reward_logits', 'policy_logits', 'value_logits'))
+    steps = list(net.dyn.steps) + list(net.pred.steps)
+    perms = {}
+    C = int(net.norm_groups)
+    can = getattr(net, 'kind', '') == 'resnet' and C % 16 == 0 and H % C == 0
+    if plane_major is None:
+        plane_major = can
+    if plane_major and not can:
+        raise ValueError('plane-major storage needs a board network whose channel count is a multiple of 16')
+    if plane_major:
+        p = plane_major_permutation(C, H // C)
+        perms = {s.out: p for s in steps if int(s.W.shape[0]) == H}
+        perms['hidden'] = p
+        perms['xa'] = np.concatenate([p, H + np.arange(asz)])
+    pm = pack_mfma(steps, {'xa': H + asz}, {'hidden': ('xa', 0, H)},
+                   keep=('next_raw', 'reward_logits', 'policy_logits', 'value_logits'), perms=perms)
+    pm.plane_major = int(bool(plane_major))
     io = np.asarray([pm.slots['xa'], pm.slots['xa'] + H, pm.slots['next_raw'], pm.slots['reward_logits'],
                      pm.slots['policy_logits'], pm.slots['value_logits'], H, net.A, asz,
                      2 * net.support_limit + 1, net.norm_groups, net.obs_size], np.int32)

@@ -25,6 +25,9 @@ for _ in range(2):
     eng.search_mfma()
 buf = np.zeros((B, S), np.int32)
 lib().mz_debug_read_path(C.c_void_p(eng._ctx), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes))
-st = buf.view(np.int64).reshape(B, S // 2)[:, :4].astype(np.float64)
-print('cycles per simulation (clock64 ticks), mean over trees: descend+stage %.0f  barrier wait %.0f  network %.0f  epilogue+backup %.0f  total %.0f'
-      % (*(st.mean(0) / S), st.sum(1).mean() / S))
+cached = os.environ.get('MZ_SEARCH_CACHED', '1') != '0'
+n = 5 if cached else 4
+st = buf.view(np.int64).reshape(B, S // 2)[:, :n].astype(np.float64)
+names = ['walk/descend+stage', 'barrier wait', 'network', 'epilogue+backup'] + (['decisions'] if cached else [])
+print('clock64 ticks (100 MHz) per simulation, mean over trees: ' +
+      '  '.join('%s %.0f' % (k, v) for k, v in zip(names, st.mean(0) / S)) + '  total %.0f' % (st.sum(1).mean() / S))
