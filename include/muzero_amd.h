@@ -143,16 +143,18 @@ int mz_set_network(mz_ctx *ctx, const int32_t *meta_h, int32_t n_meta, const flo
 
 /* Uploads the same kind of network in matrix-core layout (muzero_amd/packing.py, pack_mfma) for the
  * batched leaf evaluation of mz_expand_backup_net: any lowered network whose 32-tree activation tile
- * fits in LDS, e.g. MuZeroResidualNetwork (network.py:133-186) on a 3x3 board.  steps_h int32[n_steps*12],
- * tiles_h int32[n_tiles*2], level_start_h int32[n_levels+1], wfrag_h float[n_w] (the stored 16x16 weight
- * blocks in v_mfma_f32_16x16x4_f32 operand order; all-zero blocks are left out), bias_h float[n_b],
- * ctinfo_h int32[n_jobs*3] = per (step, column tile) {weight offset in floats, first entry in kidx, number
- * of blocks}, kidx_h int32[n_kidx] = the 16-input block index of every stored block, stride = activation
- * floats per tree, plane_major != 0: the program keeps the hidden state as [cell][channel] with io_h[10]
- * channels (stored hidden states stay [channel][cell] as in the reference), io_h as in mz_set_network. */
-int mz_set_network_mfma(mz_ctx *ctx, const int32_t *steps_h, int32_t n_steps, const int32_t *tiles_h,
-                        int32_t n_tiles, const int32_t *level_start_h, int32_t n_levels, const float *wfrag_h,
-                        int64_t n_w, const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
+ * fits in LDS, e.g. MuZeroResidualNetwork (network.py:133-186) on a 3x3 board.  steps_h int32[n_steps*12]
+ * (one dense layer each, in n_levels dependency levels), sched_h int32[n_sched] = the host-made assignment of
+ * every level's (step, column tile) jobs to the waves of a 32-tree and of a 16-tree block, wfrag_h float[n_w]
+ * (the stored 16x16 weight blocks in v_mfma_f32_16x16x4_f32 operand order; all-zero blocks are left out),
+ * bias_h float[n_b], ctinfo_h int32[n_jobs*3] = per (step, column tile) {weight offset in floats, first entry
+ * in kidx, number of blocks}, kidx_h int32[n_kidx] = the 16-input block index of every stored block, stride =
+ * activation floats per tree, plane_major != 0: the program keeps the hidden state as [cell][channel] with
+ * io_h[10] channels (stored hidden states stay [channel][cell] as in the reference), io_h as in mz_set_network.
+ * The table layouts are documented in muzero_amd/packing.py. */
+int mz_set_network_mfma(mz_ctx *ctx, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
+                        const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
+                        const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
                         const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
                         const int32_t *io_h);
 

@@ -3,30 +3,63 @@ from __future__ import annotations
 
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuzero_amd.so')
-SOURCES = ['engine.hip']
+OBJ_DIR = os.path.join(HERE, 'build')
+# translation units: the C ABI with the tree / fused-network kernels, and the matrix-core kernels
+SOURCES = ['engine.hip', 'mfma_kernels.hip']
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'muzero_amd.h')]
 # -ffp-contract=off: the tree arithmetic must round exactly like the reference's NumPy expressions.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17']
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False) -> str:
-    if force or needs_build():
+# headers a translation unit does NOT include (everything else counts as a dependency)
+NOT_INCLUDED = {'engine.hip': {'net_mfma.h', 'search_cached.h'},
+                'mfma_kernels.hip': {'search_net.h', 'search_reg.h', 'env_step.h', 'targets.h'}}
+
+
+def _stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src] + [h for h in HEADERS if os.path.basename(h) not in NOT_INCLUDED.get(src, set())]
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in deps)
+
+
+def build(force: bool = False, defines=(), lib: str = LIB) -> str:
+    """Compiles the translation units that changed (all of them with `force`), in parallel, and links the shared
+    library.  `defines`: extra -D flags (the diagnostic build with phase stamps uses MZ_STAMPS and another `lib`)."""
+    if force or needs_build(lib):
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        cmd = [hipcc, *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], '-o', LIB]
-        subprocess.check_call(cmd)
-    return LIB
+        tag = '_'.join(defines)
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        objs = [os.path.join(OBJ_DIR, s.replace('.hip', f'{"_" + tag if tag else ""}.o')) for s in SOURCES]
+        dflags = [f'-D{x}' for x in defines]
+        todo = [(s, o) for s, o in zip(SOURCES, objs) if force or _stale(s, o)]
+
+        def compile_one(pair):
+            src, obj = pair
+            subprocess.check_call([hipcc, *FLAGS, *dflags, '-c', os.path.join(CSRC, src), '-o', obj])
+        with ThreadPoolExecutor(max(len(todo), 1)) as pool:
+            list(pool.map(compile_one, todo))
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib])
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force=True))
+    import sys
+    force = '--changed' not in sys.argv
+    if '--stamps' in sys.argv:
+        print(build(force=force, defines=('MZ_STAMPS',), lib=os.path.join(HERE, 'libmuzero_amd_stamps.so')))
+    else:
+        print(build(force=force))

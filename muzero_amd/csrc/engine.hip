@@ -16,9 +16,8 @@
 #include "../../include/muzero_amd.h"
 #include "tree_kernels.h"  // device_common.h, tree_ops.h
 #include "dense_net.h"
-#include "net_mfma.h"      // matrix-core leaf evaluation; uses the epilogue helpers of dense_net.h
+#include "mfma_launch.h"   // matrix-core leaf evaluation and searches, compiled in mfma_kernels.hip
 #include "search_net.h"
-#include "search_cached.h"
 #include "search_reg.h"
 #include "env_step.h"
 #include "targets.h"
@@ -55,7 +54,7 @@ struct mz_ctx {
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
     MfmaNet mnet;       // MFMA-layout network (mz_set_network_mfma)
-    void *mnet_bufs[9];  // steps, tiles, level_start, wfrag, bias, per-level job table, global activations, ctinfo, kidx
+    void *mnet_bufs[9];  // steps, per-wave schedules, (unused), wfrag, bias, per-level job table, global activations, ctinfo, kidx
     int mnet_max_k16;                  // widest layer input in blocks of 16 floats
     std::vector<int> mnet_level_job0;  // first block of each level in the job table (+ total at the end)
     bool mnet_tile_fits;               // a 16-tree activation tile fits in LDS (tile-resident kernels usable)
@@ -277,7 +276,7 @@ static int check_ctx(mz_ctx *c, const char *fn)
 // hipFuncSetAttribute costs microseconds of host time per call: the dynamic LDS limit of a kernel is raised only when
 // a launch needs more than an earlier one was granted.  The limit belongs to (device, function), and contexts of several
 // devices or host threads may launch at once, hence the key and the lock.
-static hipError_t ensure_dynamic_lds(const void *kern, size_t bytes)
+hipError_t mz::ensure_dynamic_lds(const void *kern, size_t bytes)
 {
     static std::mutex mu;
     static std::map<std::pair<int, const void *>, size_t> granted;
@@ -396,44 +395,19 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
         if (c->rl > 16) return fail(MZ_ERR_ARG, "mz_search_run: the matrix-core search serves at most 16 actions; use the step API");
         // Gumbel trees whose record layout the decision-caching kernel is built for (9 actions: the 3x3 board games)
         // walk down cached decisions and re-decide only the nodes a simulation changed (search_cached.h).
-        {
-            using GL = GumbelLayout<9>;
-            const Layout &L = c->d.L;
-            bool cached = c->cfg.gumbel && L.A == 9 && L.idx16 && L.rec == GL::rec && L.off_crew == GL::off_crew &&
-                          L.off_prior == GL::off_prior && L.off_cvis == GL::off_cvis && L.off_cidx == GL::off_cidx;
-            if (const char *e = getenv("MZ_SEARCH_CACHED")) cached = cached && atoi(e) != 0;
-            int ctm = 32;
-            if (const char *e = getenv("MZ_SEARCH_TM")) ctm = atoi(e) == 16 ? 16 : 32;
-            const size_t stat = (size_t)ctm * 16 * 8 + (size_t)ctm * 9 * 8 + (size_t)ctm * 24 + 64;
-            const size_t dyn = ((size_t)c->mnet.stride + L.N + L.S) * ctm * 4;
-            if (cached && dyn + stat <= 160 * 1024) {
-                auto kern = ctm == 32 ? k_search_gcache<32, 9> : k_search_gcache<16, 9>;
-                if (ensure_dynamic_lds(reinterpret_cast<const void *>(kern), dyn) != hipSuccess)
-                    return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
-                hipLaunchKernelGGL(kern, dim3((c->B + ctm - 1) / ctm), dim3(ctm * 16), dyn, (hipStream_t)stream, c->d, c->mnet,
-                                   c->n_expanded + 1, n_sims);
-                c->n_expanded += n_sims;
-                return launch_status("mz_search_run");
-            }
-        }
-        // 32-tree tiles: 16-tree tiles (two or three blocks per CU) were measured no faster - each weight
-        // fragment then serves one row block instead of two
-        constexpr int tm = 32;
-        const size_t lds = (size_t)c->mnet.stride * tm * 4;
-        if (lds + (size_t)tm * 16 * 8 > 160 * 1024)
-            return fail(MZ_ERR_ARG, "mz_search_run: activations of a 32-tree tile do not fit in LDS beside the backup staging; use the step API");
-        hipError_t attr_err = hipSuccess;
-        auto launch = [&](auto kern) {
-            attr_err = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)lds);
-            hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream,
-                               c->d, c->mnet, c->n_expanded + 1, n_sims, noise, (int)noise_max_calls);
-        };
-        const bool g = c->cfg.gumbel != 0;
-        switch (c->rl) {
-        case 2: if (g) launch(k_search_mfma<tm, 2, true>); else launch(k_search_mfma<tm, 2, false>); break;
-        case 4: if (g) launch(k_search_mfma<tm, 4, true>); else launch(k_search_mfma<tm, 4, false>); break;
-        case 8: if (g) launch(k_search_mfma<tm, 8, true>); else launch(k_search_mfma<tm, 8, false>); break;
-        default: if (g) launch(k_search_mfma<tm, 16, true>); else launch(k_search_mfma<tm, 16, false>); break;
+        int ctm = 32;
+        if (const char *e = getenv("MZ_SEARCH_TM")) ctm = atoi(e) == 16 ? 16 : 32;
+        bool cached = c->cfg.gumbel && search_gcache_supported(c->d, c->mnet, ctm);
+        if (const char *e = getenv("MZ_SEARCH_CACHED")) cached = cached && atoi(e) != 0;
+        hipError_t attr_err;
+        if (cached) {
+            attr_err = launch_search_gcache(ctm, (hipStream_t)stream, c->d, c->mnet, c->n_expanded + 1, n_sims);
+        } else {
+            // 32-tree tiles: 16-tree tiles (two or three blocks per CU) were measured no faster
+            if ((size_t)c->mnet.stride * 32 * 4 + (size_t)32 * 16 * 8 > 160 * 1024)
+                return fail(MZ_ERR_ARG, "mz_search_run: activations of a 32-tree tile do not fit in LDS beside the backup staging; use the step API");
+            attr_err = launch_search_mfma(c->rl, c->cfg.gumbel != 0, (hipStream_t)stream, c->d, c->mnet, c->n_expanded + 1, n_sims,
+                                          noise, (int)noise_max_calls);
         }
         if (attr_err != hipSuccess) return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
         c->n_expanded += n_sims;
@@ -939,16 +913,16 @@ extern "C" int mz_debug_read_path(mz_ctx *c, void *out_h, size_t n_bytes)
 }
 #endif
 
-extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_steps, const int32_t *tiles_h,
-                                   int32_t n_tiles, const int32_t *level_start_h, int32_t n_levels,
-                                   const float *wfrag_h, int64_t n_w, const float *bias_h, int32_t n_b,
-                                   const int32_t *ctinfo_h, int32_t n_jobs, const int32_t *kidx_h, int32_t n_kidx,
-                                   int32_t stride, int32_t plane_major, const int32_t *io_h)
+extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
+                                   const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
+                                   const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
+                                   const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
+                                   const int32_t *io_h)
 {
     int rc = check_ctx(c, "mz_set_network_mfma");
     if (rc) return rc;
-    if (!steps_h || !tiles_h || !level_start_h || !wfrag_h || !bias_h || !ctinfo_h || !kidx_h || !io_h || n_steps < 1 ||
-        n_tiles < 1 || n_levels < 1 || n_jobs < 1 || n_kidx < 1)
+    if (!steps_h || !sched_h || !wfrag_h || !bias_h || !ctinfo_h || !kidx_h || !io_h || n_steps < 1 ||
+        n_sched < 4 || n_levels < 1 || n_jobs < 1 || n_kidx < 1)
         return fail(MZ_ERR_ARG, "mz_set_network_mfma: null/empty program");
     if (io_h[6] != c->cfg.hidden_size || io_h[7] != c->cfg.n_actions)
         return fail(MZ_ERR_ARG, "mz_set_network_mfma: network hidden size / action count differ from the context's");
@@ -956,7 +930,7 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     if (plane_major && io_h[10] < 8) return fail(MZ_ERR_ARG, "mz_set_network_mfma: plane-major storage needs at least 8 normalisation groups (channels)");
     if (stride % 8 != 4) return fail(MZ_ERR_ARG, "mz_set_network_mfma: stride must be 4 times an odd number");
     if (stride > (1 << 20)) return fail(MZ_ERR_ARG, "mz_set_network_mfma: unreasonable activation row");
-    if (level_start_h[n_levels] != n_tiles) return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent tile table");
+    if (n_w < 1 || n_w > (1 << 28) || n_b < 1) return fail(MZ_ERR_ARG, "mz_set_network_mfma: weight or bias array out of range");
     for (int s = 0; s < n_steps; s++) {
         const int32_t *st = steps_h + 12 * s;
         int k16 = st[2], nct = st[9];
@@ -972,10 +946,39 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
                     return fail(MZ_ERR_ARG, "mz_set_network_mfma: a weight block lies outside its layer's inputs");
         }
     }
-    for (int i = 0; i < n_tiles; i++)
-        if (tiles_h[2 * i] < 0 || tiles_h[2 * i] >= n_steps || tiles_h[2 * i + 1] < 0 ||
-            tiles_h[2 * i + 1] >= steps_h[12 * tiles_h[2 * i] + 9])
-            return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad tile entry");
+    // the two per-wave schedules: job ranges in order, at most 64 jobs per wave, every descriptor inside its buffers
+    for (int k = 0; k < 2; k++) {
+        const int nw = k == 0 ? 8 : 4;
+        const int64_t o_start = sched_h[2 * k], o_desc = sched_h[2 * k + 1];
+        const int64_t lim_desc = k == 0 ? sched_h[2] : n_sched;
+        if (o_start < 4 || o_start + (int64_t)nw * (n_levels + 1) > o_desc || o_desc > lim_desc || lim_desc > n_sched)
+            return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent schedule offsets");
+        const int32_t *ws = sched_h + o_start, *wd = sched_h + o_desc;
+        const int64_t n_wd = (lim_desc - o_desc) / MZ_DESC_INTS;
+        int64_t prev = 0;
+        for (int w = 0; w < nw; w++) {
+            for (int l = 0; l <= n_levels; l++) {
+                const int64_t v = ws[w * (n_levels + 1) + l];
+                if (v < prev || v > n_wd) return fail(MZ_ERR_ARG, "mz_set_network_mfma: schedule job ranges out of order");
+                prev = v;
+            }
+            if (ws[w * (n_levels + 1) + n_levels] - ws[w * (n_levels + 1)] > 64)
+                return fail(MZ_ERR_ARG, "mz_set_network_mfma: more than 64 jobs for one wave");
+        }
+        for (int64_t j = 0; j < n_wd; j++) {
+            const int32_t *q = wd + MZ_DESC_INTS * j;
+            const bool ok = q[0] >= 0 && q[0] % 4 == 0 && q[1] >= 0 && (int64_t)q[0] / 4 + (int64_t)q[1] * 256 <= n_w &&
+                            q[2] >= 0 && q[2] <= 2 && (k == 0 || q[2] == 1) && q[3] >= 0 && q[3] + 16 <= stride &&
+                            q[4] >= 0 && q[4] + 16 <= stride && q[5] + 16 <= stride && q[6] >= 0 && q[6] <= 2 &&
+                            q[7] >= 0 && q[8] >= 1 && q[8] <= 16 && q[7] + q[8] <= n_b && q[9] >= 0 && q[9] + q[1] <= n_kidx;
+            if (!ok) return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad schedule entry");
+            for (int i = 0; i < q[1] && i < 12; i++) {
+                const int kb = (q[10 + i / 4] >> (8 * (i % 4))) & 0xff;
+                if (q[3] + kb * 16 + 16 > stride || kb != kidx_h[q[9] + i])
+                    return fail(MZ_ERR_ARG, "mz_set_network_mfma: a schedule entry reads outside the activation row");
+            }
+        }
+    }
     // job table of the per-level path: blocks of up to MZ_LVL_WAVES column tiles of one step, level by level
     std::vector<int32_t> jobs;
     std::vector<int> job0(1, 0);
@@ -993,9 +996,8 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
         }
         job0.push_back((int)jobs.size() / 3);
     }
-    for (int i = 0; i < n_tiles; i++)
-        if (steps_h[12 * tiles_h[2 * i]] < 0 || steps_h[12 * tiles_h[2 * i]] >= n_levels)
-            return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad level");
+    for (int s2 = 0; s2 < n_steps; s2++)
+        if (steps_h[12 * s2] < 0 || steps_h[12 * s2] >= n_levels) return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad level");
     for (void *&p : c->mnet_bufs) if (p) { (void)hipFree(p); p = nullptr; }
     c->mnet_level_job0 = job0;
     c->mnet_max_k16 = 1;
@@ -1006,19 +1008,24 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     const size_t act_rows = ((size_t)c->cfg.max_batch + 31) / 32 * 32;
     HIPCHK(hipMalloc(&c->mnet_bufs[6], act_rows * stride * 4));
     HIPCHK(hipMemset(c->mnet_bufs[6], 0, act_rows * stride * 4));
-    const void *src[5] = {steps_h, tiles_h, level_start_h, wfrag_h, bias_h};
-    size_t n[5] = {(size_t)n_steps * 12, (size_t)n_tiles * 2, (size_t)n_levels + 1, (size_t)n_w, (size_t)n_b};
-    for (int i = 0; i < 5; i++) {
-        HIPCHK(hipMalloc(&c->mnet_bufs[i], n[i] * 4));
-        HIPCHK(hipMemcpy(c->mnet_bufs[i], src[i], n[i] * 4, hipMemcpyHostToDevice));
+    const void *src[4] = {steps_h, sched_h, wfrag_h, bias_h};
+    size_t n[4] = {(size_t)n_steps * 12, (size_t)n_sched, (size_t)n_w, (size_t)n_b};
+    const int slot[4] = {0, 1, 3, 4};
+    for (int i = 0; i < 4; i++) {
+        HIPCHK(hipMalloc(&c->mnet_bufs[slot[i]], n[i] * 4));
+        HIPCHK(hipMemcpy(c->mnet_bufs[slot[i]], src[i], n[i] * 4, hipMemcpyHostToDevice));
     }
     HIPCHK(hipMalloc(&c->mnet_bufs[7], (size_t)n_jobs * 12));
     HIPCHK(hipMemcpy(c->mnet_bufs[7], ctinfo_h, (size_t)n_jobs * 12, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->mnet_bufs[8], (size_t)n_kidx * 4));
     HIPCHK(hipMemcpy(c->mnet_bufs[8], kidx_h, (size_t)n_kidx * 4, hipMemcpyHostToDevice));
     MfmaNet &m = c->mnet;
-    m.steps = (const int32_t *)c->mnet_bufs[0]; m.tiles = (const int32_t *)c->mnet_bufs[1];
-    m.level_start = (const int32_t *)c->mnet_bufs[2]; m.wfrag = (const float *)c->mnet_bufs[3];
+    m.steps = (const int32_t *)c->mnet_bufs[0];
+    const int32_t *sched_d = (const int32_t *)c->mnet_bufs[1];
+    m.wstart8 = sched_d + sched_h[0]; m.wdesc8 = sched_d + sched_h[1];
+    m.wstart4 = sched_d + sched_h[2]; m.wdesc4 = sched_d + sched_h[3];
+    m.w_bytes = (int)(n_w * 4); m.b_bytes = n_b * 4;
+    m.wfrag = (const float *)c->mnet_bufs[3];
     m.bias = (const float *)c->mnet_bufs[4];
     m.ctinfo = (const int32_t *)c->mnet_bufs[7]; m.kidx = (const int32_t *)c->mnet_bufs[8];
     m.plane_major = plane_major ? 1 : 0;
@@ -1056,34 +1063,17 @@ static int expand_backup_net_impl(mz_ctx *c, int32_t select_next, const double *
     if (by_level) {
         float *acts = stg.acts;
         const int32_t *jobs = (const int32_t *)c->mnet_bufs[5];
-        const unsigned tree_tiles = (unsigned)((c->B + 31) / 32);
         const size_t lds = (size_t)(c->mnet_max_k16 * 16 + 4) * 32 * 4;
-        HIPCHK(ensure_dynamic_lds(reinterpret_cast<const void *>(&k_net_level<true>), lds));
-        HIPCHK(ensure_dynamic_lds(reinterpret_cast<const void *>(&k_net_level<false>), lds));
         for (int l = 0; l < c->mnet.n_levels; l++) {
             const int j0 = c->mnet_level_job0[l], nb = c->mnet_level_job0[l + 1] - j0;
             if (nb < 1) continue;
-            if (l == 0)
-                hipLaunchKernelGGL(k_net_level<true>, dim3(nb, tree_tiles), dim3(MZ_LVL_WAVES * 64), lds, (hipStream_t)stream, c->d, c->mnet,
-                                   jobs + 3 * j0, acts);
-            else
-                hipLaunchKernelGGL(k_net_level<false>, dim3(nb, tree_tiles), dim3(MZ_LVL_WAVES * 64), lds, (hipStream_t)stream, c->d, c->mnet,
-                                   jobs + 3 * j0, acts);
+            HIPCHK(launch_net_level(l == 0, (unsigned)nb, lds, (hipStream_t)stream, c->d, c->mnet, jobs + 3 * j0, acts));
         }
         // a whole wave per tree when the supports or the hidden state are long
-        if (c->mnet.io[9] > 64 || c->mnet.io[6] / c->mnet.io[10] > 64)
-            hipLaunchKernelGGL(k_net_epilogue<64>, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, c->d, c->mnet, leaf,
-                               (const float *)acts, stg.logits, stg.value, stg.reward);
-        else
-            hipLaunchKernelGGL(k_net_epilogue<16>, dim3((c->B + 15) / 16), dim3(256), 0, (hipStream_t)stream, c->d, c->mnet, leaf,
-                               (const float *)acts, stg.logits, stg.value, stg.reward);
+        const int ep_lanes = (c->mnet.io[9] > 64 || c->mnet.io[6] / c->mnet.io[10] > 64) ? 64 : 16;
+        launch_net_epilogue(ep_lanes, (hipStream_t)stream, c->d, c->mnet, leaf, acts, stg.logits, stg.value, stg.reward);
     } else {
-        size_t lds = (size_t)c->mnet.stride * tm * 4;
-        auto kern = tm == 32 ? k_net_step<32> : k_net_step<16>;
-        // per launch, like the other kernels with large dynamic LDS: the attribute belongs to the current device
-        HIPCHK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)lds));
-        hipLaunchKernelGGL(kern, dim3((c->B + tm - 1) / tm), dim3(tm * 16), lds, (hipStream_t)stream, c->d,
-                           c->mnet, leaf, stg.logits, stg.value, stg.reward);
+        HIPCHK(launch_net_step(tm, (hipStream_t)stream, c->d, c->mnet, leaf, stg.logits, stg.value, stg.reward));
     }
     if ((rc = launch_status("mz_expand_backup_net"))) return rc;
     if (select_next) {

@@ -1,0 +1,82 @@
+// The matrix-core kernels (net_mfma.h, search_cached.h) and their launch functions, compiled apart from the C ABI layer.
+#include "search_cached.h"  // net_mfma.h, dense_net.h, tree_kernels.h
+
+namespace mz {
+
+hipError_t launch_net_step(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int leaf, float *logits, double *value,
+                           double *reward)
+{
+    const size_t lds = (size_t)net.stride * tm * 4;
+    auto kern = tm == 32 ? k_net_step<32> : k_net_step<16>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((d.B + tm - 1) / tm), dim3(tm * 16), lds, st, d, net, leaf, logits, value, reward);
+    return hipSuccess;
+}
+
+hipError_t launch_net_level(bool first, unsigned n_blocks, size_t lds, hipStream_t st, const Dev &d, const MfmaNet &net,
+                            const int32_t *jobs, float *acts)
+{
+    auto kern = first ? k_net_level<true> : k_net_level<false>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks, (unsigned)((d.B + 31) / 32)), dim3(MZ_LVL_WAVES * 64), lds, st, d, net, jobs, acts);
+    return hipSuccess;
+}
+
+void launch_net_epilogue(int lanes, hipStream_t st, const Dev &d, const MfmaNet &net, int leaf, const float *acts,
+                         float *logits, double *value, double *reward)
+{
+    if (lanes == 64)
+        hipLaunchKernelGGL(k_net_epilogue<64>, dim3((d.B + 3) / 4), dim3(256), 0, st, d, net, leaf, acts, logits, value, reward);
+    else
+        hipLaunchKernelGGL(k_net_epilogue<16>, dim3((d.B + 15) / 16), dim3(256), 0, st, d, net, leaf, acts, logits, value, reward);
+}
+
+hipError_t launch_search_mfma(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf,
+                              int n_sims, const double *noise, int noise_max_calls)
+{
+    constexpr int tm = 32;
+    const size_t lds = (size_t)net.stride * tm * 4;
+    hipError_t err = hipSuccess;
+    auto launch = [&](auto kern) {
+        err = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+        if (err == hipSuccess)
+            hipLaunchKernelGGL(kern, dim3((d.B + tm - 1) / tm), dim3(tm * 16), lds, st, d, net, first_leaf, n_sims, noise,
+                               noise_max_calls);
+    };
+    switch (rl) {
+    case 2: if (gumbel) launch(k_search_mfma<tm, 2, true>); else launch(k_search_mfma<tm, 2, false>); break;
+    case 4: if (gumbel) launch(k_search_mfma<tm, 4, true>); else launch(k_search_mfma<tm, 4, false>); break;
+    case 8: if (gumbel) launch(k_search_mfma<tm, 8, true>); else launch(k_search_mfma<tm, 8, false>); break;
+    default: if (gumbel) launch(k_search_mfma<tm, 16, true>); else launch(k_search_mfma<tm, 16, false>); break;
+    }
+    return err;
+}
+
+static size_t gcache_dynamic_lds(const Dev &d, const MfmaNet &net, int tm)
+{
+    return ((size_t)net.stride + d.L.N + d.L.S) * tm * 4;
+}
+
+bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm)
+{
+    using GL = GumbelLayout<9>;
+    const Layout &L = d.L;
+    const bool layout = L.prior_f32 && L.A == 9 && L.idx16 && L.rec == GL::rec && L.off_crew == GL::off_crew &&
+                        L.off_prior == GL::off_prior && L.off_cvis == GL::off_cvis && L.off_cidx == GL::off_cidx;
+    const size_t stat = (size_t)tm * 16 * 8 + (size_t)tm * 9 * 8 + (size_t)tm * 24 + 64;  // the kernel's static arrays
+    return layout && (tm == 32 || tm == 16) && gcache_dynamic_lds(d, net, tm) + stat <= 160 * 1024;
+}
+
+hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims)
+{
+    const size_t lds = gcache_dynamic_lds(d, net, tm);
+    auto kern = tm == 32 ? k_search_gcache<32, 9> : k_search_gcache<16, 9>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((d.B + tm - 1) / tm), dim3(tm * 16), lds, st, d, net, first_leaf, n_sims);
+    return hipSuccess;
+}
+
+}  // namespace mz

@@ -11,24 +11,13 @@
 // output, same rounding class as the reference's float32 network.
 #pragma once
 #include "dense_net.h"
+#include "mfma_launch.h"
 
 namespace mz {
 
 #define MZ_NET_TM 32
 #define MZ_NET_NT 512  // 8 waves: two per SIMD, so one wave's weight-load and LDS waits hide behind the other's MFMAs
 
-struct MfmaNet {
-    const int32_t *steps;        // 12 ints per step
-    const int32_t *tiles;        // (step, column tile) pairs
-    const int32_t *level_start;  // [n_levels + 1]
-    const float *wfrag;
-    const float *bias;
-    const int32_t *ctinfo;       // per (step, column tile) job: weight offset (floats), first entry in kidx, number of blocks
-    const int32_t *kidx;         // 16-input block indices of the jobs' stored blocks
-    int n_steps, n_levels, stride;
-    int plane_major;             // the hidden state inside the activation row is [cell][channel] (channels = io[10])
-    int io[12];  // in_hidden, in_action, out_next, out_reward, out_policy, out_value, H, A, action_size, support, norm_groups, obs
-};
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -43,7 +32,7 @@ __device__ __forceinline__ float apply_act(float v, int act)
 // supplies, for the j-th of four k-steps of a 16-wide k block, A[row r][k = 16*blk + 4q + j] (four
 // consecutive floats of its tree's activations: one 16-byte LDS read) and the matching weight
 // W[col][same k] (one 16-byte global read of the pre-swizzled fragment).
-#define MZ_WPF 10  // weight fragments prefetched per job (k blocks of 16; larger K runs in rounds of this)
+#define MZ_WPF 10  // weight blocks fetched per round (k blocks of 16; a job with more runs in rounds of this)
 // HALVES = 2: both 16-row halves of the tile from one pass over the weights (two accumulator chains);
 // HALVES = 1: only half `half` (finer jobs, used to even out levels whose tile count does not divide
 // by the number of waves).
@@ -106,6 +95,186 @@ __device__ __forceinline__ void mfma_tile(const MfmaNet &net, const float *in, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Tile-resident evaluation (activations of the block's trees in LDS), software-pipelined per wave.
+// The wave's jobs come from the host-made schedule (muzero_amd/packing.py).  Their descriptors are read once per
+// kernel into registers - lane j keeps job j - and fetched with lane reads, so a job costs no table loads.  While a
+// job's matrix instructions run, the weights of the wave's NEXT job (of this level or a later one: weights do not
+// depend on activations) are already on their way: every job issues exactly MZ_WPF weight loads and one bias load
+// through buffer descriptors, blocks it does not have are addressed out of range (the hardware returns zero without
+// touching memory), so the number of loads in flight is a compile-time fact and the wait for the current job's
+// weights never waits for the next job's.  Inside a job the LDS reads of block i+1 are issued before the matrix
+// instructions of block i.
+struct TileSched {
+    int f[MZ_DESC_INTS];  // lane j: descriptor of the wave's j-th job
+    int lvl_end;          // lane l: number of the wave's jobs in levels 0..l
+    int n_jobs;           // wave-uniform
+};
+
+struct WReg {
+    float4 w[MZ_WPF];
+    float bias;
+};
+
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+
+// (element reads go through scalars: __builtin_bit_cast applied to a vector element directly reads element 0 with this compiler)
+__device__ __forceinline__ float4 as_float4(u32x4 v)
+{
+    const unsigned a = v[0], b = v[1], c = v[2], d = v[3];
+    return make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d));
+}
+
+struct NetBufs {
+    __amdgpu_buffer_rsrc_t w, b;
+};
+
+__device__ __forceinline__ NetBufs net_bufs(const MfmaNet &net)
+{
+    NetBufs r;
+    r.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(net.wfrag), 0, net.w_bytes, 0x00020000);
+    r.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(net.bias), 0, net.b_bytes, 0x00020000);
+    return r;
+}
+
+template <int TM>
+__device__ __forceinline__ void tile_sched_load(const MfmaNet &net, int wave_v, int lane, TileSched &ts)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+    const int32_t *ws = (TM == 32 ? net.wstart8 : net.wstart4) + wave * (net.n_levels + 1);
+    const int32_t *wd = TM == 32 ? net.wdesc8 : net.wdesc4;
+    const int base = ws[0];
+    ts.n_jobs = ws[net.n_levels] - base;
+#pragma unroll
+    for (int k = 0; k < MZ_DESC_INTS; k++) ts.f[k] = lane < ts.n_jobs ? wd[(base + lane) * MZ_DESC_INTS + k] : 0;
+    ts.lvl_end = lane < net.n_levels ? ws[lane + 1] - base : ts.n_jobs;
+}
+
+__device__ __forceinline__ int sched_get(const TileSched &ts, int field, int job)
+{
+    return __builtin_amdgcn_readlane(ts.f[field], job);
+}
+
+// Issues the loads of job `job` (exactly MZ_WPF + 1 of them whatever the job's size); job >= n_jobs: all out of range.
+__device__ __forceinline__ void tile_wload(const NetBufs &nb, const TileSched &ts, int job, int lane, WReg &r)
+{
+    const bool real = job < ts.n_jobs;
+    const int jj = real ? job : 0;
+    const int w_off = sched_get(ts, 0, jj), nkb = real ? sched_get(ts, 1, jj) : 0, b_col = sched_get(ts, 7, jj);
+    const int ncols = real ? sched_get(ts, 8, jj) : 0;
+#pragma unroll
+    for (int i = 0; i < MZ_WPF; i++) {
+        const int voff = i < nkb ? lane * 16 + i * 1024 : 0x7ffffff0;
+        r.w[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, voff, w_off, 0));
+    }
+    const int boff = (lane & 15) < ncols ? (lane & 15) * 4 : 0x7ffffff0;
+    r.bias = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(nb.b, boff, b_col * 4, 0));
+}
+
+// NKB blocks of one job, straight-line: the activations of block i + 1 are read while block i multiplies.
+template <int NKB, int HALVES>
+__device__ __forceinline__ void mfma_blocks(const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
+                                            const int (&kb)[MZ_WPF], f32x4 &acc0, f32x4 &acc1)
+{
+    float4 x0 = *reinterpret_cast<const float4 *>(a0 + kb[0] * 16);
+    float4 x1 = {0, 0, 0, 0};
+    if constexpr (HALVES == 2) x1 = *reinterpret_cast<const float4 *>(a1 + kb[0] * 16);
+#pragma unroll
+    for (int i = 0; i < NKB; i++) {
+        float4 n0 = x0, n1 = x1;
+        if (i + 1 < NKB) {
+            n0 = *reinterpret_cast<const float4 *>(a0 + kb[i + 1] * 16);
+            if constexpr (HALVES == 2) n1 = *reinterpret_cast<const float4 *>(a1 + kb[i + 1] * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of block i + 1 ahead of block i's matrix instructions
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, w[i].x, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w[i].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, w[i].y, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, w[i].z, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w[i].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, w[i].w, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w[i].w, acc1, 0, 0, 0);
+        x0 = n0; x1 = n1;
+    }
+}
+
+template <int HALVES>
+__device__ __forceinline__ void mfma_round(int n, const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
+                                           const int (&kb)[MZ_WPF], f32x4 &acc0, f32x4 &acc1)
+{
+    switch (n) {
+    case 1: mfma_blocks<1, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 2: mfma_blocks<2, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 3: mfma_blocks<3, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 4: mfma_blocks<4, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 5: mfma_blocks<5, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 6: mfma_blocks<6, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 7: mfma_blocks<7, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 8: mfma_blocks<8, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 9: mfma_blocks<9, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    case 10: mfma_blocks<10, HALVES>(a0, a1, w, kb, acc0, acc1); break;
+    default: break;
+    }
+}
+
+// One scheduled job on the LDS-resident tile; `first`: its first MZ_WPF weight blocks and bias, loaded ahead.
+template <int TM>
+__device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, float *act, const TileSched &ts, int job,
+                                         int lane, const WReg &first)
+{
+    const int w_off = sched_get(ts, 0, job), nkb = sched_get(ts, 1, job), mode = sched_get(ts, 2, job);
+    const int in_off = sched_get(ts, 3, job), out_col = sched_get(ts, 4, job), skip_col = sched_get(ts, 5, job);
+    const int actf = sched_get(ts, 6, job), ncols = sched_get(ts, 8, job);
+    const int p[3] = {sched_get(ts, 10, job), sched_get(ts, 11, job), sched_get(ts, 12, job)};
+    int kb[MZ_WPF];
+#pragma unroll
+    for (int i = 0; i < MZ_WPF; i++) kb[i] = (p[i / 4] >> (8 * (i % 4))) & 0xff;
+    const int row0 = mode == 2 ? 16 : 0;
+    float *base = act + (row0 + (lane & 15)) * net.stride;
+    const float *a0 = base + in_off + (lane >> 4) * 4;
+    const float *a1 = a0 + 16 * net.stride;
+    const bool both = TM == 32 && mode == 0;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    const int n0 = nkb < MZ_WPF ? nkb : MZ_WPF;
+    if (both) mfma_round<2>(n0, a0, a1, first.w, kb, acc0, acc1);
+    else mfma_round<1>(n0, a0, a1, first.w, kb, acc0, acc1);
+    if (nkb > MZ_WPF) {  // wide layers: further rounds, loaded here (their latency is exposed)
+        const int32_t *kx = net.kidx + sched_get(ts, 9, job);
+        for (int k0 = MZ_WPF; k0 < nkb; k0 += MZ_WPF) {
+            float4 w[MZ_WPF];
+            int kb2[MZ_WPF];
+#pragma unroll
+            for (int i = 0; i < MZ_WPF; i++) {
+                const bool has = k0 + i < nkb;
+                const int voff = has ? lane * 16 + (k0 + i) * 1024 : 0x7ffffff0;
+                w[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, voff, w_off, 0));
+                kb2[i] = has ? kx[k0 + i] : 0;
+            }
+            const int n = nkb - k0 < MZ_WPF ? nkb - k0 : MZ_WPF;
+            if (both) mfma_round<2>(n, a0, a1, w, kb2, acc0, acc1);
+            else mfma_round<1>(n, a0, a1, w, kb2, acc0, acc1);
+        }
+    }
+    // C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + register
+    const int c = lane & 15;
+    if (c < ncols) {
+        const float b = first.bias;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float *o0 = act + (row0 + (lane >> 4) * 4 + j) * net.stride, *o1 = o0 + 16 * net.stride;
+            float v0 = acc0[j] + b;
+            if (skip_col >= 0) v0 += o0[skip_col + c];
+            o0[out_col + c] = apply_act(v0, actf);
+            if (both) {
+                float v1 = acc1[j] + b;
+                if (skip_col >= 0) v1 += o1[skip_col + c];
+                o1[out_col + c] = apply_act(v1, actf);
+            }
+        }
+    }
+}
+
 // Shared pieces of the two kernels below.  A block of MZ_NET_NT threads owns a tile of MZ_NET_TM trees;
 // tree i of the tile is also served by the 16-lane group i (threads 16 i .. 16 i + 15) for everything
 // that is per tree: staging its inputs, the epilogue, and (whole-search kernel) its tree operations.
@@ -139,32 +308,20 @@ __device__ __forceinline__ void tile_stage_inputs(const MfmaNet &net, float *row
     for (int j = a; j < asz; j += 16) row[net.io[1] + j] = j == action ? 1.0f : 0.0f;
 }
 
-// all levels of the program for a tile of TM (32 or 16) trees; ends with a workgroup barrier
+// all levels of the program for a tile of TM (32 or 16) trees; ends with a workgroup barrier.  `w0`: the loads of the
+// wave's first job, issued by the caller with tile_wload(.., 0, ..) before it waited for the tile's inputs.
 template <int TM>
-__device__ __forceinline__ void tile_run_levels(const MfmaNet &net, float *act, int wave_v, int lane)
+__device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBufs &nb, float *act, const TileSched &ts,
+                                                int lane, WReg &w0)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(wave_v);  // wave-uniform: job tables are then read with scalar loads
+    int job = 0;
     for (int l = 0; l < net.n_levels; l++) {
-        constexpr int NW = TM * 16 / 64;
-        const int first = net.level_start[l], n_tiles = net.level_start[l + 1] - first;
-        if constexpr (TM == 16) {  // one 16-row block per column tile
-            for (int ti = wave; ti < n_tiles; ti += NW) {
-                const int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
-                mfma_tile<1>(net, act, net.stride, net.steps[12 * s + 3], act, net.stride, net.steps + 12 * s, ct, 0, lane);
-            }
-            __syncthreads();
-            continue;
-        }
-        // whole tiles while they fill every wave; the remainder is dealt as half tiles
-        const int n_whole = n_tiles / NW * NW;
-        for (int ti = wave; ti < n_whole; ti += NW) {
-            int s = net.tiles[2 * (first + ti)], ct = net.tiles[2 * (first + ti) + 1];
-            mfma_tile<2>(net, act, net.stride, net.steps[12 * s + 3], act, net.stride, net.steps + 12 * s, ct, 0, lane);
-        }
-        for (int j = wave; j < 2 * (n_tiles - n_whole); j += NW) {
-            int ti = first + n_whole + (j >> 1);
-            int s = net.tiles[2 * ti], ct = net.tiles[2 * ti + 1];
-            mfma_tile<1>(net, act, net.stride, net.steps[12 * s + 3], act, net.stride, net.steps + 12 * s, ct, j & 1, lane);
+        const int lend = __builtin_amdgcn_readlane(ts.lvl_end, l);
+        for (; job < lend; job++) {
+            WReg w1;
+            tile_wload(nb, ts, job + 1, lane, w1);
+            tile_job<TM>(net, nb, act, ts, job, lane, w0);
+            w0 = w1;
         }
         __syncthreads();
     }
@@ -217,8 +374,13 @@ __global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int le
         int parent = d.sel_parent[t], action = d.sel_action[t];
         tile_stage_inputs(net, row, d.hidden + ((long long)t * d.L.N + parent) * H, action, a);
     }
+    const NetBufs nb = net_bufs(net);
+    TileSched ts;
+    tile_sched_load<TM>(net, wave, lane, ts);
+    WReg wf;
+    tile_wload(nb, ts, 0, lane, wf);
     __syncthreads();
-    tile_run_levels<TM>(net, act, wave, lane);
+    tile_run_levels<TM>(net, nb, act, ts, lane, wf);
     if (!live) return;
     double value, reward;
     tile_epilogue(net, row, a, d.hidden + ((long long)t * d.L.N + leaf) * H, &value, &reward);
@@ -236,7 +398,6 @@ __global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int le
 // jobs: int32 [n_blocks][3] = (step, first column tile, number of column tiles <= MZ_LVL_WAVES).
 // FIRST: the level reads the network's inputs, which are taken straight from the trees (hidden state of
 // each tree's selected parent + encoded action, mcts/mcts.py:240-243) instead of `acts`.
-#define MZ_LVL_WAVES 8  // column tiles (= waves) per block of the per-level kernel
 template <bool FIRST>
 __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level(Dev d, MfmaNet net, const int32_t *jobs, float *acts)
 {
@@ -322,6 +483,9 @@ __global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int
     DescendCtx dc = descend_ctx<GUMBEL>(d, tt, a, on, nullptr, nullptr);
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[tt];
     long long visited = 0;
+    const NetBufs nb = net_bufs(net);
+    TileSched ts;
+    tile_sched_load<TM>(net, wave, lane, ts);
     __syncthreads();
 #ifdef MZ_STAMPS
     long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_t = clock64();
@@ -338,9 +502,11 @@ __global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int
             tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
         }
         MZ_MSTAMP(st_a)
+        WReg wf;
+        tile_wload(nb, ts, 0, lane, wf);
         __syncthreads();
         MZ_MSTAMP(st_b)
-        tile_run_levels<TM>(net, act, wave, lane);
+        tile_run_levels<TM>(net, nb, act, ts, lane, wf);
         MZ_MSTAMP(st_c)
         if (live) {
             double value, reward;

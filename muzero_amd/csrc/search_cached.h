@@ -263,6 +263,9 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
         s_items[i] = live ? first_leaf : 0;
     }
     long long visited = 0;
+    const NetBufs nb = net_bufs(net);
+    TileSched ts;
+    tile_sched_load<TM>(net, wave, lane, ts);
     __syncthreads();
     const char *tile_nodes = d.nodes + (long long)blockIdx.x * TM * d.L.tree_stride;
     // every node that already exists (a fresh search: the roots)
@@ -303,9 +306,11 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
         }
         MZ_MSTAMP(st_a)
+        WReg wf;
+        tile_wload(nb, ts, 0, lane, wf);
         __syncthreads();
         MZ_MSTAMP(st_b)
-        tile_run_levels<TM>(net, act, wave, lane);
+        tile_run_levels<TM>(net, nb, act, ts, lane, wf);
         MZ_MSTAMP(st_c)
         if (live) {
             double value, reward;

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64) void k_node_op(Dev d, int t, int node, int dept
 }
 
 // MCTS.backward (mcts/mcts.py:143-164) from an arbitrary node, walking the parent links; one lane.
-__global__ void k_node_backward(Dev d, int t, int leaf, int to_play)
+static __global__ void k_node_backward(Dev d, int t, int leaf, int to_play)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const TreeMem m = tree_mem(d, t);
@@ -389,7 +389,7 @@ __global__ void k_node_backward(Dev d, int t, int leaf, int to_play)
     }
 }
 
-__global__ void k_stats(Dev d, long long *out_node_visits, int32_t *out_noise_calls)
+static __global__ void k_stats(Dev d, long long *out_node_visits, int32_t *out_noise_calls)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= d.B) return;

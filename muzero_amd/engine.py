@@ -83,7 +83,7 @@ def lib():
         L.mz_search_run_act.argtypes = [vp, i32, vp, vp, i32, C.c_double, vp, vp, vp, vp, vp, vp]
         L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
-        L.mz_set_network_mfma.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, C.c_int64, vp, i32, vp, i32, vp, i32, i32, i32, vp]
+        L.mz_set_network_mfma.argtypes = [vp, vp, i32, i32, vp, i32, vp, C.c_int64, vp, i32, vp, i32, vp, i32, i32, i32, vp]
         L.mz_expand_backup_net.argtypes = [vp, i32, vp, i32, vp]
         L.mz_expand_backup_net_static.argtypes = [vp, i32, vp, i32, vp]
         L.mz_act_env_step.argtypes = [vp, C.POINTER(MzEnvState), f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -308,8 +308,8 @@ class SearchEngine:
         """Uploads a network in matrix-core layout (muzero_amd.packing.pack_network_mfma)."""
         self._mfma_keep = (pm, io)
         vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
-        _check(lib().mz_set_network_mfma(self._ctx, vp(pm.steps), pm.steps.size // 12, vp(pm.tiles), pm.tiles.size // 2,
-                                         vp(pm.level_start), pm.level_start.size - 1, vp(pm.wfrag),
+        _check(lib().mz_set_network_mfma(self._ctx, vp(pm.steps), pm.steps.size // 12, int(pm.n_levels),
+                                         vp(pm.sched), int(pm.sched.size), vp(pm.wfrag),
                                          C.c_int64(pm.wfrag.size), vp(pm.bias), int(pm.bias.size),
                                          vp(pm.ctinfo), pm.ctinfo.size // 3, vp(pm.kidx), int(pm.kidx.size),
                                          int(pm.stride), int(pm.plane_major), vp(io)))

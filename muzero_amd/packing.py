@@ -153,13 +153,25 @@ def pack_network(net) -> PackedNetwork:
 # int32 step table, 12 ints per step:
 #   level, N, K16 (= ceil(K/16)), in_off, out_off, skip_off (-1), act, w_off (floats, first job), b_off (floats),
 #   n_col_tiles, first job in ctinfo, 0
-# int32 tile table: (step, ct) pairs ordered by level, inside a level by falling block count in serpentine order
-# over 8 waves (the waves of a block take the entries round-robin); level_start[l] .. level_start[l+1] index it.
+# Work of a tile-resident block is scheduled on the host: within a level the (step, ct) jobs are dealt to the block's
+# waves longest-first onto the least loaded wave, and a job of a 32-tree tile may be split into its two 16-row halves
+# when that evens the waves out.  `sched` holds two schedules (8 waves = 32-tree tiles, 4 waves = 16-tree tiles):
+#   sched[0:4] = offsets inside sched of wstart8, wdesc8, wstart4, wdesc4
+#   wstartW[wave * (n_levels + 1) + l] .. [.. + l + 1] = the wave's jobs of level l (numbers of descriptors in wdescW);
+#   a wave's jobs are contiguous over the levels (at most 64 per wave: a wave keeps its descriptors in registers)
+#   wdescW[DESC_INTS * j ..] = one job, everything its wave needs without further table reads:
+#     0 byte offset of its first weight block   1 number of blocks   2 mode (0: both 16-row halves, 1: rows 0..15,
+#     2: rows 16..31)   3 input offset   4 first output column (floats in the activation row)   5 first residual
+#     column or -1   6 activation   7 first bias entry   8 valid columns (1..16)   9 first entry in kidx
+#     10..12 the first 12 block indices, one byte each
+DESC_INTS = 13
+
+
 @dataclass
 class PackedMfma:
     steps: np.ndarray        # int32 [n_steps * 12]
-    tiles: np.ndarray        # int32 [n_tiles * 2]
-    level_start: np.ndarray  # int32 [n_levels + 1]
+    n_levels: int
+    sched: np.ndarray        # int32, the two per-wave schedules
     wfrag: np.ndarray        # float32, the stored blocks
     bias: np.ndarray         # float32 (each step padded to 16 columns)
     stride: int              # activation floats per tree (4 x an odd number: conflict-free 16-byte operand reads)
@@ -271,16 +283,16 @@ def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple]
         macs += N * K
         dense += nct * 16 * k16 * 16
     n_levels = max(per_level) + 1 if per_level else 0
-    tiles, level_start = [], [0]
-    for lv in range(n_levels):
-        jobs = sorted(per_level.get(lv, []), key=lambda x: (-x[0], x[1], x[2]))
-        for r in range(0, len(jobs), 8):       # serpentine: every second round of 8 in rising order
-            chunk = jobs[r:r + 8]
-            if (r // 8) % 2:
-                chunk = chunk[::-1]
-            for (_, si, ct) in chunk:
-                tiles += [si, ct]
-        level_start.append(len(tiles) // 2)
+    parts = []
+    for n_waves, may_split in ((8, True), (4, False)):
+        wstart, wjobs = _schedule(per_level, n_levels, n_waves, may_split)
+        parts.append((wstart, _descriptors(wjobs, table, ctinfo, kidx)))
+    sched, off = [0, 0, 0, 0], 4
+    for k, (wstart, wdesc) in enumerate(parts):
+        sched[2 * k], sched[2 * k + 1] = off, off + len(wstart)
+        off += len(wstart) + len(wdesc)
+    for wstart, wdesc in parts:
+        sched += wstart + wdesc
     # an input is read in blocks of 16 floats, i.e. up to 15 floats past its own end, where the weights
     # are zero but the values must exist: the row covers the furthest such read
     tab = np.asarray(table, np.int64).reshape(-1, 12)
@@ -289,9 +301,68 @@ def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple]
     if stride % 8 == 0:
         stride += 4                      # 4 x odd: rows start 4 x (odd multiple) banks apart
     wfrag = np.concatenate(wblobs) if wblobs else np.zeros(256, np.float32)
-    return PackedMfma(np.asarray(table, np.int32), np.asarray(tiles, np.int32), np.asarray(level_start, np.int32),
+    return PackedMfma(np.asarray(table, np.int32), n_levels, np.asarray(sched, np.int32),
                       np.ascontiguousarray(wfrag, np.float32), np.concatenate(bblobs), int(stride), slots, macs, padded,
                       np.asarray(ctinfo, np.int32), np.asarray(kidx if kidx else [0], np.int32), 0, dense)
+
+
+def _schedule(per_level, n_levels, n_waves, may_split):
+    """Longest-first assignment of each level's jobs (blocks, step, ct) to `n_waves` waves; with `may_split` a job
+    that covers both 16-row halves of a 32-tree tile can give one half to the least loaded wave.  Cost model: 8 matrix
+    instructions per block for both halves, 4 for one, plus a fixed cost per job (output stores, table reads).
+    Returns (wstart, wjobs) as flat int lists."""
+    cost = lambda nkb, mode: (8 if mode == 0 else 4) * nkb + 6  # noqa: E731
+    per_wave = [[[] for _ in range(n_levels)] for _ in range(n_waves)]
+    for lv in range(n_levels):
+        load = [0] * n_waves
+        for nkb, si, ct in sorted(per_level.get(lv, []), key=lambda x: (-x[0], x[1], x[2])):
+            w = min(range(n_waves), key=lambda i: (load[i], i))
+            job = [nkb, si, ct, 0 if may_split else 1]
+            per_wave[w][lv].append(job)
+            load[w] += cost(nkb, job[3])
+        for _ in range(4 * n_waves if may_split else 0):
+            hi = max(range(n_waves), key=lambda i: (load[i], -i))
+            lo = min(range(n_waves), key=lambda i: (load[i], i))
+            whole = [j for j in per_wave[hi][lv] if j[3] == 0]
+            if not whole:
+                break
+            gap = load[hi] - load[lo]
+            j = min(whole, key=lambda j: abs(cost(j[0], 1) - gap / 2))
+            new_hi, new_lo = load[hi] - cost(j[0], 0) + cost(j[0], 1), load[lo] + cost(j[0], 1)
+            if max(new_hi, new_lo) >= load[hi]:
+                break
+            j[3] = 1
+            per_wave[lo][lv].append([j[0], j[1], j[2], 2])
+            load[hi], load[lo] = new_hi, new_lo
+    wstart, wjobs = [], []
+    for w in range(n_waves):
+        for lv in range(n_levels):
+            wstart.append(len(wjobs) // 3)
+            for nkb, si, ct, mode in per_wave[w][lv]:
+                wjobs += [si, ct, mode]
+        wstart.append(len(wjobs) // 3)
+        if (wstart[-1] - wstart[-1 - n_levels]) > 64:
+            raise ValueError('more than 64 matrix jobs per wave: the network is too wide for the tile-resident kernels')
+    return wstart, wjobs
+
+
+def _descriptors(wjobs, table, ctinfo, kidx):
+    """The per-job descriptors (DESC_INTS ints each) of a schedule's (step, ct, mode) triples."""
+    out = []
+    for j in range(0, len(wjobs), 3):
+        si, ct, mode = wjobs[j:j + 3]
+        st = table[12 * si:12 * si + 12]
+        w_off, kb0, nkb = ctinfo[3 * (st[10] + ct):3 * (st[10] + ct) + 3]
+        blocks = list(kidx[kb0:kb0 + nkb])[:12]
+        if any(b > 255 for b in blocks):
+            raise ValueError('a layer with more than 4096 inputs does not fit the job descriptors')
+        packed = [0, 0, 0]
+        for i, b in enumerate(blocks):
+            packed[i // 4] |= int(b) << (8 * (i % 4))
+        packed = [x - (1 << 32) if x >= (1 << 31) else x for x in packed]
+        out += [4 * w_off, nkb, mode, st[3], st[4] + 16 * ct, (st[5] + 16 * ct) if st[5] >= 0 else -1, st[6], st[8] + 16 * ct,
+                min(16, st[1] - 16 * ct), kb0] + packed
+    return out
 
 
 def plane_major_permutation(channels: int, cells: int) -> np.ndarray:
