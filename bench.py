@@ -74,6 +74,7 @@ WORKLOADS = {
     'cfg4': ('CartPole self-play 8192 envs/GPU x 50 sims PUCT, fused env step, per-step gather of root stats to rank 0 (BASELINE configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'selfplay'),
     'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), whole search in one launch, leaves evaluated on the matrix cores (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
+    'cfg3s': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, one leaf-evaluation launch + one backup/selection launch per simulation (comparison)', True, 9, 100, 2, 1, 16384, 'mfma_step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
     'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), leaves on the matrix cores, backup fused with the next selection (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma_step'),
     'cfg5t': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), leaves evaluated by torch ops (comparison)', False, 18, 200, 1, 0.997, 1024, 'step5'),
@@ -91,7 +92,7 @@ def algorithmic_bytes(node_visits_total, B, S, A, H, gumbel):
     return levels * (36 + 6 * w + A * (4 + p + 2 * w)) + B * S * (8 * H + p * A + 20 + 3 * w)
 
 
-DEFAULT_STEPS = {'cfg1': 200, 'cfg2': 2000, 'cfg3': 100, 'cfg3h': 200, 'cfg3t': 3, 'cfg4': 500, 'cfg4s': 500,
+DEFAULT_STEPS = {'cfg1': 200, 'cfg2': 2000, 'cfg3': 100, 'cfg3h': 200, 'cfg3t': 3, 'cfg3s': 20, 'cfg4': 500, 'cfg4s': 500,
                  'cfg5': 50, 'cfg5h': 200, 'cfg5t': 5}
 MIN_TIMED_S = 1.0     # repeat the block of K steps until this much timed work has accumulated
 MAX_BLOCKS = 200
@@ -201,7 +202,7 @@ def main():
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
         eng.set_network(packed)
         obs = torch.as_tensor(rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32), device=dev)
-    elif leaf in ('mfma_step', 'step5'):
+    elif leaf in ('mfma_step', 'step5') and A == 18:
         from muzero_amd.packing import pack_network_mfma
         net = MuZeroNetwork(atari_like_net_config(), seed=0).to(dev)
         H = net.H
@@ -210,7 +211,7 @@ def main():
         leaf_macs = (pm_io[0].macs, pm_io[0].padded_macs)
         eng.set_network_mfma(*pm_io)
         obs = torch.as_tensor(rng.standard_normal((B, 128)).astype(np.float32), device=dev)
-    elif leaf in ('step', 'mfma'):
+    elif leaf in ('step', 'mfma', 'mfma_step'):
         from muzero_amd.packing import pack_network_mfma
         net = MuZeroNetwork(tictactoe_net_config(), seed=0).to(dev)
         H = net.H

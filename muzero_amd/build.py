@@ -41,15 +41,14 @@ def build(force: bool = False, defines=(), lib: str = LIB) -> str:
     library.  `defines`: extra -D flags (the diagnostic build with phase stamps uses MZ_STAMPS and another `lib`)."""
     if force or needs_build(lib):
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        tag = '_'.join(defines)
         os.makedirs(OBJ_DIR, exist_ok=True)
+        tag = '_'.join(defines).replace('=', '')
         objs = [os.path.join(OBJ_DIR, s.replace('.hip', f'{"_" + tag if tag else ""}.o')) for s in SOURCES]
-        dflags = [f'-D{x}' for x in defines]
         todo = [(s, o) for s, o in zip(SOURCES, objs) if force or _stale(s, o)]
 
         def compile_one(pair):
             src, obj = pair
-            subprocess.check_call([hipcc, *FLAGS, *dflags, '-c', os.path.join(CSRC, src), '-o', obj])
+            subprocess.check_call([hipcc, *FLAGS, *[f'-D{x}' for x in defines], '-c', os.path.join(CSRC, src), '-o', obj])
         with ThreadPoolExecutor(max(len(todo), 1)) as pool:
             list(pool.map(compile_one, todo))
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib])

@@ -80,3 +80,12 @@ hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const Mfma
 }
 
 }  // namespace mz
+
+#ifdef MZ_STAMPS
+// Diagnostic build only: the per-block phase stamps of the last k_net_step launch.
+extern "C" int mz_debug_read_net_stamps(long long *out_h, int n)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(mz::mz_dbg_stamps), (size_t)n * 8) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -171,6 +171,15 @@ __device__ __forceinline__ void tile_wload(const NetBufs &nb, const TileSched &t
     r.bias = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(nb.b, boff, b_col * 4, 0));
 }
 
+// Workgroup barrier that orders LDS traffic only: global loads in flight (the weights of a later job) stay in flight
+// across it, where __syncthreads would wait for them.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // NKB blocks of one job, straight-line: the activations of block i + 1 are read while block i multiplies.
 template <int NKB, int HALVES>
 __device__ __forceinline__ void mfma_blocks(const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
@@ -323,7 +332,7 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBuf
             tile_job<TM>(net, nb, act, ts, job, lane, w0);
             w0 = w1;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -358,6 +367,12 @@ __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *r
 // outputs go to the leaf's hidden slot and to the per-tree logits/value/reward buffers that
 // k_expand_backup consumes.
 // TM = trees per block: 32, or 16 for networks whose 32-tree activation tile exceeds LDS.
+#ifdef MZ_STAMPS
+__device__ long long mz_dbg_stamps[8 * 1024];   // diagnostic build: per block [zero, schedule, stage, wait, levels, epilogue] cycles
+#define MZ_KSTAMP(k) { long long n_ = clock64(); if (tid == 0 && blockIdx.x < 1024) mz_dbg_stamps[blockIdx.x * 8 + (k)] = n_ - kst_; kst_ = n_; }
+#else
+#define MZ_KSTAMP(k)
+#endif
 template <int TM>
 __global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int leaf, float *out_logits,
                                                    double *out_value, double *out_reward)
@@ -368,22 +383,31 @@ __global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int le
     const int H = net.io[6], A = net.io[7];
     const bool live = t < d.B;
     float *row = act + i * net.stride;
+#ifdef MZ_STAMPS
+    long long kst_ = clock64();
+#endif
     tile_zero<TM>(act, net.stride, tid);
     __syncthreads();
+    MZ_KSTAMP(0)
+    const NetBufs nb = net_bufs(net);
+    TileSched ts;
+    tile_sched_load<TM>(net, wave, lane, ts);
+    MZ_KSTAMP(1)
     if (live) {
         int parent = d.sel_parent[t], action = d.sel_action[t];
         tile_stage_inputs(net, row, d.hidden + ((long long)t * d.L.N + parent) * H, action, a);
     }
-    const NetBufs nb = net_bufs(net);
-    TileSched ts;
-    tile_sched_load<TM>(net, wave, lane, ts);
     WReg wf;
     tile_wload(nb, ts, 0, lane, wf);
-    __syncthreads();
+    MZ_KSTAMP(2)
+    lds_barrier();
+    MZ_KSTAMP(3)
     tile_run_levels<TM>(net, nb, act, ts, lane, wf);
+    MZ_KSTAMP(4)
     if (!live) return;
     double value, reward;
     tile_epilogue(net, row, a, d.hidden + ((long long)t * d.L.N + leaf) * H, &value, &reward);
+    MZ_KSTAMP(5)
     for (int j = a; j < A; j += 16) out_logits[(long long)t * A + j] = row[net.io[4] + j];
     if (a == 0) { out_value[t] = value; out_reward[t] = reward; }
 }

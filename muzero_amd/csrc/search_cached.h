@@ -308,7 +308,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
         MZ_MSTAMP(st_a)
         WReg wf;
         tile_wload(nb, ts, 0, lane, wf);
-        __syncthreads();
+        lds_barrier();
         MZ_MSTAMP(st_b)
         tile_run_levels<TM>(net, nb, act, ts, lane, wf);
         MZ_MSTAMP(st_c)

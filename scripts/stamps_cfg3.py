@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, '.')
-os.environ['MUZERO_AMD_LIB'] = os.path.abspath('muzero_amd/libmuzero_amd_stamps.so')
+os.environ['MUZERO_AMD_LIB'] = os.path.abspath(os.environ.get('MZ_STAMPS_LIB', 'muzero_amd/libmuzero_amd_stamps.so'))
 import bench
 from muzero_amd.engine import SearchEngine, lib
 from muzero_amd.network import MuZeroNetwork
@@ -29,5 +29,5 @@ cached = os.environ.get('MZ_SEARCH_CACHED', '1') != '0'
 n = 5 if cached else 4
 st = buf.view(np.int64).reshape(B, S // 2)[:, :n].astype(np.float64)
 names = ['walk/descend+stage', 'barrier wait', 'network', 'epilogue+backup'] + (['decisions'] if cached else [])
-print('clock64 ticks (100 MHz) per simulation, mean over trees: ' +
+print('shader-clock cycles per simulation, mean over trees: ' +
       '  '.join('%s %.0f' % (k, v) for k, v in zip(names, st.mean(0) / S)) + '  total %.0f' % (st.sum(1).mean() / S))
