@@ -62,3 +62,20 @@ def assert_tree_equal(got, case, fields=TREE_FIELDS, hidden=True):
         ref = case['hidden_states']
         val = np.asarray(got.hidden_states).reshape(ref.shape)
         assert np.array_equal(val, ref), 'hidden_states'
+
+
+def replay_on_checker(cfg, tree, H, legal, to_play, seed=0, tree_id=0, gumbel_noise=None):
+    """The checker's single-tree search fed with the network outputs stored in a finished tree (an export of the GPU
+    engine): if the engine's tree logic is right, the checker rebuilds that very tree, whatever evaluated the leaves."""
+    from oracle import oracle as orc
+    S, A = cfg.simulations, cfg.n_actions
+    par, act = tree['parents'], tree['action_from_parent']
+    rec_logits = tree['children_prior_logits'][1:].astype(np.float32)
+    assert np.array_equal(rec_logits.astype(tree['children_prior_logits'].dtype), tree['children_prior_logits'][1:])  # float32 values
+    rec_value = tree['node_raw_values'][1:]
+    rec_reward = np.array([tree['children_rewards'][par[k], act[k]] for k in range(1, S + 1)])
+    rec_hidden = tree['hidden_states'][1:].reshape(S, H)
+    o = orc.Oracle(cfg, H)
+    o.init(tree['children_prior_logits'][0], tree['node_raw_values'][0], tree['hidden_states'][0], to_play, legal, gumbel_noise)
+    o.search(o.table_net(rec_logits, rec_value, rec_reward, rec_hidden), o.counter_noise(seed, tree_id))
+    return o
