@@ -71,7 +71,7 @@ WORKLOADS = {
     'cfg1': ('TicTacToe 1 tree x 25 sims PUCT, random-init ResNet, through the drop-in MCTS.search call with host inputs and outputs (BASELINE configs[0])', False, 9, 25, 2, 1, 1, 'dropin'),
     'cfg2': ('CartPole 256 envs x 50 sims PUCT, random-init MLP (BASELINE configs[1])', False, 2, 50, 1, 0.997, 256, 'mlp'),
     'cfg4s': ('CartPole 8192 envs x 50 sims PUCT search only, random-init MLP (configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'mlp'),
-    'cfg4': ('CartPole self-play 8192 envs/GPU x 50 sims PUCT, fused env step, per-step gather of root stats to rank 0 (BASELINE configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'selfplay'),
+    'cfg4': ('CartPole self-play 8192 envs/GPU x 50 sims PUCT, fused env step recording every move in a device move log, per-step gather of the records to rank 0 (BASELINE configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'selfplay'),
     'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), whole search in one launch, leaves evaluated on the matrix cores (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3s': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, one leaf-evaluation launch + one backup/selection launch per simulation (comparison)', True, 9, 100, 2, 1, 16384, 'mfma_step'),
@@ -305,6 +305,9 @@ def main():
             ev[i][1].record()
         return eng.to_act(temperature, u)
 
+    games_recorded = 0
+    if sp is not None and args.warmup:
+        sp.record(args.warmup)
     for _ in range(args.warmup):
         step()
     rdev = mzdist.reduce_device(dev)
@@ -314,8 +317,15 @@ def main():
         mzdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if sp is not None:
+            sp.record(args.steps)      # every move of the block goes to the device move log
         for i in range(args.steps):
             step(i)
+        if sp is not None:             # the block's finished games, listed on the device (part of the timed region)
+            try:
+                games_recorded += len(sp.harvest())
+            except ValueError:
+                pass
         torch.cuda.synchronize()
         mzdist.barrier()
         block = mzdist.max_over_ranks(time.perf_counter() - t0, rdev)   # the same number on every rank
@@ -351,6 +361,8 @@ def main():
         'node_visits_per_sec': nv_all * n_steps / elapsed,
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
         'env_steps_per_sec': (world * B * n_steps / elapsed) if leaf == 'selfplay' else None,
+        'recording': ({'where': 'device move log, written by k_act_env', 'games_recorded_rank0': games_recorded,
+                       'moves_recorded_rank0': B * n_steps} if leaf == 'selfplay' else None),
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
                                 'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],

@@ -285,8 +285,44 @@ int mz_act_env_step(mz_ctx *ctx, const mz_env_state *env_h, double temperature, 
                     int32_t *out_action, double *out_probs, double *out_root_value, float *out_obs_before,
                     float *out_reward, uint8_t *out_done, int32_t *out_to_play, void *stream);
 
-/* Finished games kept on the device, positions of game g at [game_offset[g], game_offset[g+1]): the
- * fields of GameHistory (games/game.py:83-94) as flat arrays.  HOST struct of DEVICE pointers. */
+/* The moves of B environments kept on the device in the order they were played: row k holds move k of the current
+ * collection window for every environment ([capacity][n_envs] per field), i.e. what SelfPlay.play appends to its
+ * GameHistory per move (self_play.py:107-109 -> games/game.py:99-112) plus the end-of-game flag.  Caller-owned
+ * DEVICE arrays in a HOST struct; written by mz_act_env_step_log, read by mz_log_count_games / mz_log_list_games
+ * and, through mz_trajectories, by mz_make_targets - the records never visit the host. */
+typedef struct mz_move_log {
+    int32_t capacity, n_envs, obs_size, n_actions;
+    float *observations;   /* [capacity][n_envs][obs_size] the observation stored with the move */
+    int32_t *actions;      /* [capacity][n_envs] */
+    double *rewards;       /* [capacity][n_envs] */
+    int32_t *to_plays;     /* [capacity][n_envs] */
+    double *root_values;   /* [capacity][n_envs] */
+    double *probs;         /* [capacity][n_envs][n_actions] */
+    uint8_t *done;         /* [capacity][n_envs] 1 = the game ended with this move */
+} mz_move_log;
+
+/* mz_act_env_step that also appends every environment's record to row `row` of `log_h` (0 <= row < capacity).
+ * The out_* arrays may each be NULL when the caller only wants the log. */
+int mz_act_env_step_log(mz_ctx *ctx, const mz_env_state *env_h, const mz_move_log *log_h, int32_t row,
+                        double temperature, const double *u, int32_t *out_action, double *out_probs,
+                        double *out_root_value, float *out_obs_before, float *out_reward, uint8_t *out_done,
+                        int32_t *out_to_play, void *stream);
+
+/* The finished games inside rows [0, n_rows) of a log, environment by environment and in playing order inside an
+ * environment (the batched counterpart of the game list a replay buffer accumulates, replay_buffer.py:30-57).
+ * mz_log_count_games: out_count i32[n_envs] = games of each environment that ended inside the rows (moves after an
+ * environment's last finished game belong to a game still open and are not listed).
+ * mz_log_list_games: first_game i64[n_envs] = exclusive prefix sum of those counts (the caller's scan);
+ * out_base i64[G] = index of a game's first position, out_len i32[G] = its length; position i of game g is at
+ * index out_base[g] + i * n_envs of the log's per-move arrays (see mz_trajectories.game_base). */
+int mz_log_count_games(const mz_move_log *log_h, int32_t n_rows, int32_t *out_count, void *stream);
+int mz_log_list_games(const mz_move_log *log_h, int32_t n_rows, const int64_t *first_game, int64_t *out_base,
+                      int32_t *out_len, void *stream);
+
+/* Finished games kept on the device: the fields of GameHistory (games/game.py:83-94) as per-position arrays.
+ * Flat form (game_base NULL): positions of game g at [game_offset[g], game_offset[g+1]).
+ * Strided form (game_base given, e.g. over a mz_move_log): position i of game g at game_base[g] + i *
+ * position_stride; game_offset is still the running sum of the game lengths.  HOST struct of DEVICE pointers. */
 typedef struct mz_trajectories {
     int32_t n_games, obs_size, n_actions, reserved;
     const int64_t *game_offset;     /* [n_games + 1] */
@@ -299,6 +335,8 @@ typedef struct mz_trajectories {
     const double *re_root_values;   /* [T] reanalysed_root_values, or NULL */
     const double *re_probs;         /* [T][n_actions] reanalysed_action_probabilities, or NULL */
     const uint8_t *has_reanalysed;  /* [n_games] 1 where save_reanalysed_stats was applied, or NULL */
+    const int64_t *game_base;       /* [n_games] or NULL */
+    int64_t position_stride;        /* used with game_base */
 } mz_trajectories;
 
 /* Replaces the per-game body of ReplayBuffer.sample (replay_buffer.py:70-101) for n_samples sampled

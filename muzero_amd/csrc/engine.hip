@@ -571,6 +571,8 @@ extern "C" int mz_make_targets(const mz_trajectories *tr, int32_t n_samples, con
     d.observations = tr->observations; d.actions = tr->actions; d.rewards = tr->rewards; d.to_plays = tr->to_plays;
     d.root_values = tr->root_values; d.probs = tr->probs;
     d.re_root_values = tr->re_root_values; d.re_probs = tr->re_probs; d.has_re = tr->has_reanalysed;
+    d.game_base = reinterpret_cast<const long long *>(tr->game_base); d.stride = tr->position_stride;
+    if (tr->game_base && tr->position_stride < 1) return fail(MZ_ERR_ARG, "mz_make_targets: position_stride must be positive");
     long long n = (long long)n_samples * (unroll_steps + 1);
     hipLaunchKernelGGL(k_make_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d,
                        (int)n_samples, game_idx, t, absorbed, (int)td_steps, (int)unroll_steps, gamma, gamma_pow,
@@ -1155,28 +1157,91 @@ extern "C" int mz_expand_backup_net_static(mz_ctx *c, int32_t select_next, const
     return expand_backup_net_impl(c, select_next, noise, noise_max_calls, stream, stg, true);
 }
 
+static int act_env_step(mz_ctx *c, const mz_env_state *env, const mz_move_log *log, int32_t row, double temperature,
+                        const double *u, int32_t *out_action, double *out_probs, double *out_root_value,
+                        float *out_obs_before, float *out_reward, uint8_t *out_done, int32_t *out_to_play, void *stream,
+                        const char *fn)
+{
+    int rc = check_ctx(c, fn);
+    if (rc) return rc;
+    const std::string f(fn);
+    if (c->B < 1) return fail(MZ_ERR_STATE, f + ": no tree");
+    if (!env) return fail(MZ_ERR_ARG, f + ": null argument");
+    if (!log && (!out_action || !out_probs || !out_root_value || !out_reward || !out_done || !out_to_play))
+        return fail(MZ_ERR_ARG, f + ": null argument");
+    if (env->kind != MZ_ENV_TICTACTOE && env->kind != MZ_ENV_CARTPOLE) return fail(MZ_ERR_ARG, f + ": unknown environment kind");
+    const int want_A = env->kind == MZ_ENV_TICTACTOE ? 9 : 2, want_obs = env->kind == MZ_ENV_TICTACTOE ? 27 : 4;
+    if (c->cfg.n_actions != want_A || env->obs_size != want_obs)
+        return fail(MZ_ERR_ARG, f + ": action count / observation size do not match the environment");
+    if (!env->state || !env->to_play || !env->legal || !env->cur_obs || !env->search_obs || !env->moves ||
+        (env->kind == MZ_ENV_TICTACTOE && !env->mover) || (env->kind == MZ_ENV_CARTPOLE && !env->reset_state))
+        return fail(MZ_ERR_ARG, f + ": incomplete environment state");
+    LogDev lg{};
+    if (log) {
+        if (!log->observations || !log->actions || !log->rewards || !log->to_plays || !log->root_values || !log->probs || !log->done)
+            return fail(MZ_ERR_ARG, f + ": incomplete move log");
+        if (log->n_envs != c->B || log->obs_size != env->obs_size || log->n_actions != c->cfg.n_actions)
+            return fail(MZ_ERR_ARG, f + ": move log shaped for another batch / environment");
+        if (row < 0 || row >= log->capacity) return fail(MZ_ERR_ARG, f + ": the move log is full (row outside 0..capacity-1)");
+        lg = LogDev{log->observations, log->actions, log->to_plays, log->rewards, log->root_values, log->probs, log->done,
+                    (long long)row * log->n_envs};
+    }
+    EnvDev e;
+    e.kind = env->kind; e.max_moves = env->max_moves; e.stale = env->stale_observation; e.obs_size = env->obs_size;
+    e.state = env->state; e.mover = env->mover; e.to_play = env->to_play; e.legal = env->legal;
+    e.cur_obs = env->cur_obs; e.search_obs = env->search_obs; e.moves = env->moves; e.reset_state = env->reset_state;
+    MZ_LAUNCH(c, k_act_env, true, c->B, 0, stream, c->d, e, lg, temperature, u, out_action, out_probs, out_root_value,
+              out_obs_before, out_reward, out_done, out_to_play);
+    return launch_status(fn);
+}
+
 extern "C" int mz_act_env_step(mz_ctx *c, const mz_env_state *env, double temperature, const double *u,
                                int32_t *out_action, double *out_probs, double *out_root_value,
                                float *out_obs_before, float *out_reward, uint8_t *out_done,
                                int32_t *out_to_play, void *stream)
 {
-    int rc = check_ctx(c, "mz_act_env_step");
+    return act_env_step(c, env, nullptr, 0, temperature, u, out_action, out_probs, out_root_value, out_obs_before, out_reward,
+                        out_done, out_to_play, stream, "mz_act_env_step");
+}
+
+extern "C" int mz_act_env_step_log(mz_ctx *c, const mz_env_state *env, const mz_move_log *log, int32_t row,
+                                   double temperature, const double *u, int32_t *out_action, double *out_probs,
+                                   double *out_root_value, float *out_obs_before, float *out_reward, uint8_t *out_done,
+                                   int32_t *out_to_play, void *stream)
+{
+    if (!log) return fail(MZ_ERR_ARG, "mz_act_env_step_log: null move log");
+    return act_env_step(c, env, log, row, temperature, u, out_action, out_probs, out_root_value, out_obs_before, out_reward,
+                        out_done, out_to_play, stream, "mz_act_env_step_log");
+}
+
+static int check_log(const mz_move_log *log, int32_t n_rows, const char *fn)
+{
+    if (!log || !log->done || log->n_envs < 1 || n_rows < 0 || n_rows > log->capacity)
+        return fail(MZ_ERR_ARG, std::string(fn) + ": bad move log or row count");
+    return MZ_OK;
+}
+
+extern "C" int mz_log_count_games(const mz_move_log *log, int32_t n_rows, int32_t *out_count, void *stream)
+{
+    (void)hipGetLastError();
+    int rc = check_log(log, n_rows, "mz_log_count_games");
     if (rc) return rc;
-    if (c->B < 1) return fail(MZ_ERR_STATE, "mz_act_env_step: no tree");
-    if (!env || !out_action || !out_probs || !out_root_value || !out_reward || !out_done || !out_to_play)
-        return fail(MZ_ERR_ARG, "mz_act_env_step: null argument");
-    if (env->kind != MZ_ENV_TICTACTOE && env->kind != MZ_ENV_CARTPOLE) return fail(MZ_ERR_ARG, "mz_act_env_step: unknown environment kind");
-    const int want_A = env->kind == MZ_ENV_TICTACTOE ? 9 : 2, want_obs = env->kind == MZ_ENV_TICTACTOE ? 27 : 4;
-    if (c->cfg.n_actions != want_A || env->obs_size != want_obs)
-        return fail(MZ_ERR_ARG, "mz_act_env_step: action count / observation size do not match the environment");
-    if (!env->state || !env->to_play || !env->legal || !env->cur_obs || !env->search_obs || !env->moves ||
-        (env->kind == MZ_ENV_TICTACTOE && !env->mover) || (env->kind == MZ_ENV_CARTPOLE && !env->reset_state))
-        return fail(MZ_ERR_ARG, "mz_act_env_step: incomplete environment state");
-    EnvDev e;
-    e.kind = env->kind; e.max_moves = env->max_moves; e.stale = env->stale_observation; e.obs_size = env->obs_size;
-    e.state = env->state; e.mover = env->mover; e.to_play = env->to_play; e.legal = env->legal;
-    e.cur_obs = env->cur_obs; e.search_obs = env->search_obs; e.moves = env->moves; e.reset_state = env->reset_state;
-    MZ_LAUNCH(c, k_act_env, true, c->B, 0, stream, c->d, e, temperature, u, out_action, out_probs, out_root_value,
-              out_obs_before, out_reward, out_done, out_to_play);
-    return launch_status("mz_act_env_step");
+    if (!out_count) return fail(MZ_ERR_ARG, "mz_log_count_games: null output");
+    hipLaunchKernelGGL(k_log_games<false>, dim3((log->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, log->done,
+                       (int)log->n_envs, (int)n_rows, out_count, (const long long *)nullptr, (long long *)nullptr,
+                       (int32_t *)nullptr);
+    return launch_status("mz_log_count_games");
+}
+
+extern "C" int mz_log_list_games(const mz_move_log *log, int32_t n_rows, const int64_t *first_game, int64_t *out_base,
+                                 int32_t *out_len, void *stream)
+{
+    (void)hipGetLastError();
+    int rc = check_log(log, n_rows, "mz_log_list_games");
+    if (rc) return rc;
+    if (!first_game || !out_base || !out_len) return fail(MZ_ERR_ARG, "mz_log_list_games: null argument");
+    hipLaunchKernelGGL(k_log_games<true>, dim3((log->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, log->done,
+                       (int)log->n_envs, (int)n_rows, (int32_t *)nullptr, reinterpret_cast<const long long *>(first_game),
+                       reinterpret_cast<long long *>(out_base), out_len);
+    return launch_status("mz_log_list_games");
 }

@@ -18,6 +18,15 @@ struct EnvDev {
     const double *reset_state;
 };
 
+// Rows of a move log (mz_move_log); pointers NULL = no log.
+struct LogDev {
+    float *observations;
+    int32_t *actions, *to_plays;
+    double *rewards, *root_values, *probs;
+    uint8_t *done;
+    long long row_base;   // row * n_envs
+};
+
 // games/tictactoe.py:14-81 + games/game.py:56-74.  Returns terminated; winner: -2 = none yet.
 __device__ __forceinline__ bool tictactoe_step(signed char *b, int *mover, int action, float *reward)
 {
@@ -68,7 +77,7 @@ __device__ __forceinline__ bool cartpole_step(double *s, int action)
 }
 
 template <int LANES, int RL, bool GUMBEL>
-__global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, double temperature, const double *u,
+__global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, LogDev lg, double temperature, const double *u,
                                                        int32_t *out_action, double *out_probs,
                                                        double *out_root_value, float *out_obs_before,
                                                        float *out_reward, uint8_t *out_done,
@@ -80,14 +89,22 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, double te
     bool on = a < A;
     double prob, qout, rv;
     int action = to_act_rule<RL, GUMBEL>(d, tree_mem(d, t), t, a, on, temperature, u ? u[t] : 0.0, &prob, &qout, &rv);
-    if (on) out_probs[(long long)t * A + a] = prob;
+    const long long lr = lg.row_base + t;   // this environment's slot in the log row
+    if (on) {
+        if (out_probs) out_probs[(long long)t * A + a] = prob;
+        if (lg.probs) lg.probs[lr * A + a] = prob;
+    }
     if (a != 0) return;
-    out_action[t] = action;
-    out_root_value[t] = rv;
-    out_to_play[t] = e.to_play[t];
+    if (out_action) out_action[t] = action;
+    if (out_root_value) out_root_value[t] = rv;
+    if (out_to_play) out_to_play[t] = e.to_play[t];
     float *cur = e.cur_obs + (long long)t * OS, *srch = e.search_obs + (long long)t * OS;
     uint8_t *legal = e.legal + (long long)t * A;
     if (out_obs_before) for (int i = 0; i < OS; i++) out_obs_before[(long long)t * OS + i] = cur[i];
+    if (lg.actions) {
+        for (int i = 0; i < OS; i++) lg.observations[lr * OS + i] = cur[i];
+        lg.actions[lr] = action; lg.to_plays[lr] = e.to_play[t]; lg.root_values[lr] = rv;
+    }
     // the reference searches the NEXT move from the observation saved with this one (self_play.py:86-91,108)
     if (e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
     float reward;
@@ -106,7 +123,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, double te
         e.to_play[t] = mover == -1 ? 0 : 1;
         tictactoe_observe(b, mover, cur, legal);
         if (done || !e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
-        out_done[t] = done;
+        if (out_done) out_done[t] = done;
+        if (lg.done) lg.done[lr] = done;
     } else {
         double *s = reinterpret_cast<double *>(e.state) + (long long)t * 4;
         term = cartpole_step(s, action);
@@ -120,9 +138,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, double te
         e.moves[t] = moves;
         for (int i = 0; i < 4; i++) cur[i] = (float)s[i];
         if (done || !e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
-        out_done[t] = done;
+        if (out_done) out_done[t] = done;
+        if (lg.done) lg.done[lr] = done;
     }
-    out_reward[t] = reward;
+    if (out_reward) out_reward[t] = reward;
+    if (lg.rewards) lg.rewards[lr] = (double)reward;
 }
 
 }  // namespace mz

@@ -47,10 +47,16 @@ class MzEnvState(C.Structure):
                 ('reset_state', C.c_void_p)]
 
 
+class MzMoveLog(C.Structure):
+    _fields_ = [('capacity', C.c_int32), ('n_envs', C.c_int32), ('obs_size', C.c_int32), ('n_actions', C.c_int32),
+                ('observations', C.c_void_p), ('actions', C.c_void_p), ('rewards', C.c_void_p), ('to_plays', C.c_void_p),
+                ('root_values', C.c_void_p), ('probs', C.c_void_p), ('done', C.c_void_p)]
+
+
 ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_set_seed', 'mz_check', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_expand_backup_net_static', 'mz_act_env_step', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_expand_backup_net_static', 'mz_act_env_step', 'mz_act_env_step_log', 'mz_log_count_games', 'mz_log_list_games', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
@@ -87,6 +93,10 @@ def lib():
         L.mz_expand_backup_net.argtypes = [vp, i32, vp, i32, vp]
         L.mz_expand_backup_net_static.argtypes = [vp, i32, vp, i32, vp]
         L.mz_act_env_step.argtypes = [vp, C.POINTER(MzEnvState), f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.mz_act_env_step_log.argtypes = [vp, C.POINTER(MzEnvState), C.POINTER(MzMoveLog), i32, f64, vp, vp, vp, vp, vp, vp,
+                                          vp, vp, vp]
+        L.mz_log_count_games.argtypes = [C.POINTER(MzMoveLog), i32, vp, vp]
+        L.mz_log_list_games.argtypes = [C.POINTER(MzMoveLog), i32, vp, vp, vp, vp]
         L.mz_search_begin_net.argtypes = [vp, i32, vp, vp, vp, vp, f64, vp, u64, vp, vp, vp]
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
         L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
@@ -396,15 +406,19 @@ class SearchEngine:
                                _ptr(q), _stream()))
         return action, value, probs, q
 
-    def act_env_step(self, env_struct, temperature, u, out):
+    def act_env_step(self, env_struct, temperature, u, out, log=None, row=0):
         """Final action rule + environment step + trajectory record + restart of finished games.
-        `out`: dict of preallocated device tensors action/probs/value/obs_before/reward/done/to_play."""
+        `out`: dict of preallocated device tensors action/probs/value/obs_before/reward/done/to_play (with a
+        log it may be None or hold only some of them); log: MzMoveLog whose row `row` receives the records."""
         uu = None if u is None else self._dev(u, torch.float64).reshape(self.B)
         self._u_keep = uu
-        _check(lib().mz_act_env_step(self._ctx, C.byref(env_struct), float(temperature), _ptr(uu),
-                                     _ptr(out['action']), _ptr(out['probs']), _ptr(out['value']),
-                                     _ptr(out.get('obs_before')), _ptr(out['reward']), _ptr(out['done']),
-                                     _ptr(out['to_play']), _stream()))
+        out = out or {}
+        outs = [_ptr(out.get(k)) for k in ('action', 'probs', 'value', 'obs_before', 'reward', 'done', 'to_play')]
+        if log is None:
+            _check(lib().mz_act_env_step(self._ctx, C.byref(env_struct), float(temperature), _ptr(uu), *outs, _stream()))
+        else:
+            _check(lib().mz_act_env_step_log(self._ctx, C.byref(env_struct), C.byref(log), int(row), float(temperature),
+                                             _ptr(uu), *outs, _stream()))
 
     def check(self):
         """Waits for the stream and raises EngineError if a kernel flagged an inconsistent state or a noise

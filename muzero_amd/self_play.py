@@ -4,8 +4,9 @@ The loop of the reference's `SelfPlay.play` (self_play.py:77-115) for a whole ba
 search from each game's observation, act, step the game, record the move, restart finished games.
 Per move this is three launches on the fused path (root inference + root rows, all simulations with
 in-kernel leaf evaluation, action rule + environment step); trees and environments never leave HBM.
-Trajectories are handed back per step in the reference's `GameHistory.save` record layout and can be
-turned into `GameHistory` objects for a replay buffer.
+Every move's record (the fields of `GameHistory.save`) is appended by the action + environment kernel to a
+device move log; finished games are read from it in place by `TrajectoryStore.from_log`, or copied out once
+as `GameHistory` objects for a host replay buffer.
 """
 from __future__ import annotations
 
@@ -17,6 +18,7 @@ import torch
 from . import engine as _engine
 from . import noise as _noise
 from .games.game import GameHistory
+from .targets import MoveLog, TrajectoryStore
 
 
 class DeviceEnvs:
@@ -184,39 +186,55 @@ class BatchedSelfPlay:
                 self._root_noise()   # advances the block that also holds the sampling uniforms
             u, self._u_next = self._u_next, None
         e.refresh_reset_states()
-        eng.act_env_step(e.struct, temperature, u, self.out)
+        log = self.log
+        if log is not None and log.rows >= log.capacity:
+            raise _engine.EngineError(f'the move log is full ({log.capacity} moves per environment): read it with '
+                                      'harvest() or start a new window with record(capacity)')
+        eng.act_env_step(e.struct, temperature, u, self.out, None if log is None else log.struct,
+                         0 if log is None else log.rows)
+        if log is not None:
+            log.rows += 1
         self.steps_done += 1
         return self.out
 
     # ------------------------------------------------------------------ trajectories
-    def play(self, n_steps: int, temperature: float = 1.0, record: bool = True):
-        """Plays n_steps moves in every environment; returns finished games as GameHistory objects
-        (host) when `record` is set."""
-        B, e = self.B, self.envs
-        open_games: List[list] = [[] for _ in range(B)]
-        finished: List[GameHistory] = []
-        for _ in range(n_steps):
-            out = self.step(temperature)
-            if not record:
-                continue
-            rec = {k: v.cpu().numpy().copy() for k, v in out.items()}
-            for b in range(B):
-                open_games[b].append((rec['obs_before'][b], int(rec['action'][b]), float(rec['reward'][b]),
-                                      int(rec['to_play'][b]), rec['probs'][b], float(rec['value'][b])))
-                if rec['done'][b]:
-                    finished.append(self._history(open_games[b]))
-                    open_games[b] = []
-        return finished
+    log = None
 
-    def _history(self, moves) -> GameHistory:
+    def record(self, capacity: int) -> MoveLog:
+        """Starts a collection window: the next `capacity` moves of every environment go to a device move log
+        (re-used when its size allows).  Games still open when the window starts lose the moves already played."""
         e = self.envs
-        if e.kind == 'tictactoe':
-            shape = (3, 3, 3)
-            encoder = lambda a: np.eye(9)[a].reshape(3, 3)  # noqa: E731
+        if self.log is None or self.log.capacity < capacity:
+            shape = (3, 3, 3) if e.kind == 'tictactoe' else (1, 1, 4)
+            self.log = MoveLog(capacity, self.B, shape, e.A, self.device)
+        self.log.rows = 0
+        self.log.done.zero_()
+        return self.log
+
+    def stop_recording(self) -> None:
+        self.log = None
+
+    def harvest(self) -> TrajectoryStore:
+        """The games that finished inside the current window, as a device store over the log itself."""
+        if self.log is None:
+            raise _engine.EngineError('harvest: no collection window (call record(capacity) first)')
+        return TrajectoryStore.from_log(self.log)
+
+    def play(self, n_steps: int, temperature: float = 1.0, record: bool = True) -> List[GameHistory]:
+        """Plays n_steps moves in every environment; with `record`, returns the games that finished inside
+        them as GameHistory objects (host): the log is copied out once and sliced, no per-move transfers."""
+        if record:
+            self.record(n_steps)
         else:
-            shape = (1, 1, 4)
-            encoder = lambda a: np.eye(2)[a]  # noqa: E731
-        h = GameHistory(encoder, moves[0][0].reshape(shape))
-        for obs, a, r, tp, pi, v in moves:
-            h.save(obs.reshape(shape), a, r, tp, pi, v)
-        return h
+            self.stop_recording()
+        for _ in range(n_steps):
+            self.step(temperature)
+        if not record:
+            return []
+        try:
+            store = self.harvest()
+        except ValueError:
+            return []
+        A = self.envs.A
+        encoder = (lambda a: np.eye(9)[a].reshape(3, 3)) if self.envs.kind == 'tictactoe' else (lambda a: np.eye(A)[a])
+        return store.histories(encoder)
