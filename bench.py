@@ -1,6 +1,6 @@
 """Benchmark of the batched MCTS search (BASELINE.json metric: MCTS simulations/sec).
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3h|cfg3t|cfg4|cfg4s|cfg5|cfg5h|cfg5t]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3h|cfg3s|cfg3t|cfg4|cfg4s|cfg5|cfg5h|cfg5s|cfg5t]
 
 One process per GPU.  Under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (torchrun) the process is
 one rank; started plainly with --gpus N > 1 it starts the N ranks itself, as fresh child processes, before
@@ -76,7 +76,8 @@ WORKLOADS = {
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3s': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, one leaf-evaluation launch + one backup/selection launch per simulation (comparison)', True, 9, 100, 2, 1, 16384, 'mfma_step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
-    'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), leaves on the matrix cores, backup fused with the next selection (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma_step'),
+    'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), whole search in one call: level-by-level leaf evaluation on the matrix cores, tree ranges on streams of their own (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma'),
+    'cfg5s': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), one call per simulation: a launch per network level, epilogue, backup + next selection (comparison)', False, 18, 200, 1, 0.997, 1024, 'mfma_step'),
     'cfg5t': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), leaves evaluated by torch ops (comparison)', False, 18, 200, 1, 0.997, 1024, 'step5'),
     'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
 }
@@ -93,7 +94,7 @@ def algorithmic_bytes(node_visits_total, B, S, A, H, gumbel):
 
 
 DEFAULT_STEPS = {'cfg1': 200, 'cfg2': 2000, 'cfg3': 100, 'cfg3h': 200, 'cfg3t': 3, 'cfg3s': 20, 'cfg4': 500, 'cfg4s': 500,
-                 'cfg5': 50, 'cfg5h': 200, 'cfg5t': 5}
+                 'cfg5': 50, 'cfg5s': 20, 'cfg5h': 200, 'cfg5t': 5}
 MIN_TIMED_S = 1.0     # repeat the block of K steps until this much timed work has accumulated
 MAX_BLOCKS = 200
 
@@ -202,7 +203,7 @@ def main():
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
         eng.set_network(packed)
         obs = torch.as_tensor(rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32), device=dev)
-    elif leaf in ('mfma_step', 'step5') and A == 18:
+    elif leaf in ('mfma', 'mfma_step', 'step5') and A == 18:
         from muzero_amd.packing import pack_network_mfma
         net = MuZeroNetwork(atari_like_net_config(), seed=0).to(dev)
         H = net.H
@@ -364,7 +365,7 @@ def main():
         'recording': ({'where': 'device move log, written by k_act_env', 'games_recorded_rank0': games_recorded,
                        'moves_recorded_rank0': B * n_steps} if leaf == 'selfplay' else None),
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': 'k_search_mfma', 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
+                                'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation and tree range' if A > 16 else 'k_search_mfma'), 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,

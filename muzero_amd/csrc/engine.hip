@@ -54,7 +54,7 @@ struct mz_ctx {
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
     MfmaNet mnet;       // MFMA-layout network (mz_set_network_mfma)
-    void *mnet_bufs[9];  // steps, per-wave schedules, (unused), wfrag, bias, per-level job table, global activations, ctinfo, kidx
+    void *mnet_bufs[10];  // steps, per-wave schedules, (unused), wfrag, bias, per-level job table, global activations, ctinfo, kidx, block descriptors of the row-range level kernel
     int mnet_max_k16;                  // widest layer input in blocks of 16 floats
     std::vector<int> mnet_level_job0;  // first block of each level in the job table (+ total at the end)
     bool mnet_tile_fits;               // a 16-tree activation tile fits in LDS (tile-resident kernels usable)
@@ -375,6 +375,56 @@ extern "C" int mz_expand_backup(mz_ctx *c, const float *logits, const double *va
     return launch_status("mz_expand_backup");
 }
 
+// Whole search, level by level: per simulation one launch per network level and one tree launch (epilogue, backup,
+// next selection).  lvl_issue_first: the first selection and its network inputs, all trees.  lvl_issue_range: the
+// chain of launches for the trees of range r of n_ranges (ranges are whole 32-tree tiles).
+static int lvl_issue_first(mz_ctx *c, const double *noise, int32_t noise_max_calls, hipStream_t st)
+{
+    MZ_LAUNCH(c, k_select, false, c->B, 0, st, c->d, noise, (int)noise_max_calls, (float *)nullptr, (int32_t *)nullptr,
+              (int32_t *)nullptr);
+    launch_stage_inputs(st, c->d, c->mnet, (float *)c->mnet_bufs[6]);
+    return launch_status("mz_search_run");
+}
+
+static int lvl_issue_range(mz_ctx *c, int n_sims, const double *noise, int32_t noise_max_calls, hipStream_t rs, int r,
+                           int n_ranges)
+{
+    const MfmaNet &net = c->mnet;
+    float *acts = (float *)c->mnet_bufs[6];
+    const int32_t *desc = (const int32_t *)c->mnet_bufs[9];
+    const int tiles = (c->B + 31) / 32;
+    const int tile0 = (int)((long long)tiles * r / n_ranges), tile1 = (int)((long long)tiles * (r + 1) / n_ranges);
+    const int t_first = tile0 * 32, t_end = std::min(tile1 * 32, c->B);
+    const int first_leaf = c->n_expanded + 1;
+    for (int s = 0; s < n_sims; s++) {
+        for (int l = 0; l < net.n_levels; l++) {
+            const int j0 = c->mnet_level_job0[l], nb = c->mnet_level_job0[l + 1] - j0;
+            if (nb < 1) continue;
+            HIPCHK(launch_net_level_rows((unsigned)nb, (unsigned)(tile1 - tile0), c->mnet_max_k16, rs, net,
+                                         desc + MZ_LVL_DESC * j0, acts, t_first, l));
+        }
+        if (!launch_leaf_backup_select(c->rl, c->cfg.gumbel != 0, rs, c->d, net, t_first, t_end, first_leaf + s, acts, noise,
+                                       (int)noise_max_calls, s + 1 < n_sims))
+            return fail(MZ_ERR_ARG, "mz_search_run: unsupported action count");
+    }
+    return launch_status("mz_search_run");
+}
+
+static int search_by_level(mz_ctx *c, int n_sims, const double *noise, int32_t noise_max_calls, hipStream_t stream)
+{
+    if (c->mnet_max_k16 > MZ_LVL_KB)
+        return fail(MZ_ERR_ARG, "mz_search_run: a layer is wider than the level-by-level search serves; use the step API");
+    if (!shape_supported(64, c->rl)) return fail(MZ_ERR_ARG, "mz_search_run: unsupported action count");
+    int rc = lvl_issue_first(c, noise, noise_max_calls, stream);
+    if (rc) return rc;
+    // One range: splitting the batch into ranges on streams of their own (direct launches from one or several host
+    // threads, or one captured graph per range) was measured and never won - a launch costs the host 7 us, about
+    // half a kernel's duration, so two ranges already starve each other's streams.
+    if ((rc = lvl_issue_range(c, n_sims, noise, noise_max_calls, stream, 0, 1))) return rc;
+    c->n_expanded += n_sims;
+    return MZ_OK;
+}
+
 // mz_search_run, optionally followed by the final action rule (`act->action` non-NULL).  *act_done tells
 // whether the search kernel already ran the rule.
 static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, const double *noise,
@@ -392,7 +442,11 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
     if (n_sims <= 0) return fail(MZ_ERR_STATE, "mz_search_run: all simulations already done");
     if (net_kind == MZ_NET_MFMA) {
         if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network_mfma first)");
-        if (c->rl > 16) return fail(MZ_ERR_ARG, "mz_search_run: the matrix-core search serves at most 16 actions; use the step API");
+        // more than 16 actions, tiles that do not fit in LDS, or too few trees to give every CU a tile: level by level
+        bool by_level = c->rl > 16 || !c->mnet_tile_fits ||
+                        (size_t)c->mnet.stride * 32 * 4 + (size_t)32 * 16 * 8 > 160 * 1024;
+        if (const char *e = getenv("MZ_SEARCH_LEVELS")) by_level = by_level || atoi(e) != 0;
+        if (by_level) return search_by_level(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
         // Gumbel trees whose record layout the decision-caching kernel is built for (9 actions: the 3x3 board games)
         // walk down cached decisions and re-decide only the nodes a simulation changed (search_cached.h).
         int ctm = 32;
@@ -982,7 +1036,7 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
         }
     }
     // job table of the per-level path: blocks of up to MZ_LVL_WAVES column tiles of one step, level by level
-    std::vector<int32_t> jobs;
+    std::vector<int32_t> jobs, desc;
     std::vector<int> job0(1, 0);
     for (int l = 0; l < n_levels; l++) {
         for (int s = 0; s < n_steps; s++) {
@@ -993,7 +1047,19 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
             if ((size_t)(st[2] * 16 + 4) * 32 * 4 > 160 * 1024)
                 return fail(MZ_ERR_ARG, "mz_set_network_mfma: a layer's inputs for 32 trees exceed LDS");
             for (int ct = 0; ct < st[9]; ct += MZ_LVL_WAVES) {
-                jobs.push_back(s); jobs.push_back(ct); jobs.push_back(std::min(MZ_LVL_WAVES, st[9] - ct));
+                const int n = std::min(MZ_LVL_WAVES, st[9] - ct);
+                jobs.push_back(s); jobs.push_back(ct); jobs.push_back(n);
+                // the same block for k_net_level_rows, flattened: step fields + per-wave weight block lists
+                int32_t q[MZ_LVL_DESC] = {st[2] * 16, st[3], st[1], st[4], st[5], st[6], st[8], n, ct, 1};
+                for (int w = 0; w < n; w++) {
+                    if (st[10] + ct + w >= n_jobs) return fail(MZ_ERR_ARG, "mz_set_network_mfma: column tile table too short");
+                    const int32_t *cj = ctinfo_h + 3 * (st[10] + ct + w);
+                    if (cj[1] < 0 || cj[2] < 0 || cj[1] + cj[2] > n_kidx)
+                        return fail(MZ_ERR_ARG, "mz_set_network_mfma: column tile reads outside the block index list");
+                    q[10 + 3 * w] = cj[0] * 4; q[11 + 3 * w] = cj[2]; q[12 + 3 * w] = cj[1];
+                    for (int i = 0; i < cj[2]; i++) if (kidx_h[cj[1] + i] != i) q[9] = 0;
+                }
+                desc.insert(desc.end(), q, q + MZ_LVL_DESC);
             }
         }
         job0.push_back((int)jobs.size() / 3);
@@ -1007,6 +1073,8 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     c->mnet_tile_fits = (size_t)stride * 16 * 4 <= 160 * 1024;
     HIPCHK(hipMalloc(&c->mnet_bufs[5], jobs.size() * 4));
     HIPCHK(hipMemcpy(c->mnet_bufs[5], jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->mnet_bufs[9], desc.size() * 4));
+    HIPCHK(hipMemcpy(c->mnet_bufs[9], desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
     const size_t act_rows = ((size_t)c->cfg.max_batch + 31) / 32 * 32;
     HIPCHK(hipMalloc(&c->mnet_bufs[6], act_rows * stride * 4));
     HIPCHK(hipMemset(c->mnet_bufs[6], 0, act_rows * stride * 4));

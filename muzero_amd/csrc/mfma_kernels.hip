@@ -54,6 +54,39 @@ hipError_t launch_search_mfma(int rl, bool gumbel, hipStream_t st, const Dev &d,
     return err;
 }
 
+hipError_t launch_net_level_rows(unsigned n_jobs, unsigned n_row_tiles, int max_k16, hipStream_t st, const MfmaNet &net,
+                                 const int32_t *desc, float *acts, int row_first, int level)
+{
+    static_assert(MZ_LVL_KB == 2 * MZ_WPF, "k_net_level_rows holds one or two rounds of weight blocks");
+    const size_t lds = (size_t)(max_k16 * 16 + 4) * 32 * 4;
+    auto kern = max_k16 <= MZ_WPF ? k_net_level_rows<MZ_WPF> : k_net_level_rows<2 * MZ_WPF>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_jobs, n_row_tiles), dim3(MZ_LVL_WAVES * 64), lds, st, net, desc, acts, row_first, level);
+    return hipSuccess;
+}
+
+void launch_stage_inputs(hipStream_t st, const Dev &d, const MfmaNet &net, float *acts)
+{
+    hipLaunchKernelGGL(k_stage_inputs, dim3((d.B + 3) / 4), dim3(256), 0, st, d, net, acts);
+}
+
+bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, int t_first, int t_end,
+                               int leaf, float *acts, const double *noise, int noise_max_calls, int select_next)
+{
+    const unsigned grid = (unsigned)(((long long)(t_end - t_first) * 64 + MZ_BLOCK - 1) / MZ_BLOCK);
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(MZ_BLOCK), 0, st, d, net, t_first, t_end, leaf, acts, noise, noise_max_calls,
+                           select_next);
+    };
+#define MZ_LBS(R) case R: if (gumbel) launch(k_leaf_backup_select<R, true>); else launch(k_leaf_backup_select<R, false>); return true;
+    switch (rl) {
+    MZ_LBS(2) MZ_LBS(4) MZ_LBS(8) MZ_LBS(16) MZ_LBS(32) MZ_LBS(64)
+    default: return false;
+    }
+#undef MZ_LBS
+}
+
 static size_t gcache_dynamic_lds(const Dev &d, const MfmaNet &net, int tm)
 {
     return ((size_t)net.stride + d.L.N + d.L.S) * tm * 4;

@@ -45,5 +45,14 @@ hipError_t launch_search_mfma(int rl, bool gumbel, hipStream_t st, const Dev &d,
 // kernel is built for this tree layout and fits in LDS with tm-tree tiles.
 bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm);
 hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims);
+// Whole searches level by level over ranges of trees (k_net_level_rows, k_stage_inputs, k_leaf_backup_select).
+#define MZ_LVL_DESC 40  // ints per block descriptor of k_net_level_rows: KK, in_off, N, out_off, skip_off, act, bias_off,
+                        // n column tiles, first column tile, dense flag, then per wave: weight byte offset, blocks, kidx offset
+#define MZ_LVL_KB 20   // widest layer input, in blocks of 16, that k_net_level_rows keeps in a wave's registers
+hipError_t launch_net_level_rows(unsigned n_jobs, unsigned n_row_tiles, int max_k16, hipStream_t st, const MfmaNet &net,
+                                 const int32_t *desc, float *acts, int row_first, int level);
+void launch_stage_inputs(hipStream_t st, const Dev &d, const MfmaNet &net, float *acts);
+bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, int t_first, int t_end,
+                               int leaf, float *acts, const double *noise, int noise_max_calls, int select_next);
 
 }  // namespace mz

@@ -15,6 +15,16 @@
 
 namespace mz {
 
+#ifdef MZ_STAMPS
+__device__ long long mz_dbg_stamps[8 * 1024];   // diagnostic build: cycles per phase, 8 slots per block
+#define MZ_KSTAMP(k) { long long n_ = clock64(); if (tid == 0 && blockIdx.x < 1024) mz_dbg_stamps[blockIdx.x * 8 + (k)] = n_ - kst_; kst_ = n_; }
+// the same for kernels that name their slot themselves (slot < 0: none)
+#define MZ_SSTAMP(slot, k) { long long n_ = clock64(); if ((slot) >= 0) mz_dbg_stamps[(slot) * 8 + (k)] = n_ - kst_; kst_ = n_; }
+#else
+#define MZ_KSTAMP(k)
+#define MZ_SSTAMP(slot, k)
+#endif
+
 #define MZ_NET_TM 32
 #define MZ_NET_NT 512  // 8 waves: two per SIMD, so one wave's weight-load and LDS waits hide behind the other's MFMAs
 
@@ -301,20 +311,21 @@ __device__ __forceinline__ void tile_zero(float *act, int stride, int tid)
 
 // inputs of one tree: hidden state of its selected PARENT and the encoded action (mcts/mcts.py:240-243).  Stored hidden
 // states are [channel][cell]; a plane-major network wants [cell][channel] in its activation row.
+template <int LANES = 16>
 __device__ __forceinline__ void tile_stage_inputs(const MfmaNet &net, float *row, const float *ph, int action, int a)
 {
     const int H = net.io[6], asz = net.io[8];
     if (net.plane_major) {
         const int C = net.io[10], P = H / C;
-        for (int j = a; j < H; j += 16) row[net.io[0] + (j % P) * C + j / P] = ph[j];
+        for (int j = a; j < H; j += LANES) row[net.io[0] + (j % P) * C + j / P] = ph[j];
     } else if ((H & 3) == 0) {
         const float4 *p4 = reinterpret_cast<const float4 *>(ph);
         float4 *r4 = reinterpret_cast<float4 *>(row + net.io[0]);
-        for (int j = a; j < H / 4; j += 16) r4[j] = p4[j];
+        for (int j = a; j < H / 4; j += LANES) r4[j] = p4[j];
     } else {
-        for (int j = a; j < H; j += 16) row[net.io[0] + j] = ph[j];
+        for (int j = a; j < H; j += LANES) row[net.io[0] + j] = ph[j];
     }
-    for (int j = a; j < asz; j += 16) row[net.io[1] + j] = j == action ? 1.0f : 0.0f;
+    for (int j = a; j < asz; j += LANES) row[net.io[1] + j] = j == action ? 1.0f : 0.0f;
 }
 
 // all levels of the program for a tile of TM (32 or 16) trees; ends with a workgroup barrier.  `w0`: the loads of the
@@ -367,12 +378,6 @@ __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *r
 // outputs go to the leaf's hidden slot and to the per-tree logits/value/reward buffers that
 // k_expand_backup consumes.
 // TM = trees per block: 32, or 16 for networks whose 32-tree activation tile exceeds LDS.
-#ifdef MZ_STAMPS
-__device__ long long mz_dbg_stamps[8 * 1024];   // diagnostic build: per block [zero, schedule, stage, wait, levels, epilogue] cycles
-#define MZ_KSTAMP(k) { long long n_ = clock64(); if (tid == 0 && blockIdx.x < 1024) mz_dbg_stamps[blockIdx.x * 8 + (k)] = n_ - kst_; kst_ = n_; }
-#else
-#define MZ_KSTAMP(k)
-#endif
 template <int TM>
 __global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int leaf, float *out_logits,
                                                    double *out_value, double *out_reward)
@@ -480,6 +485,227 @@ __global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int le
     else tile_epilogue<LANES, LANES>(net, row, a, hidden_dst, &value, &reward);
     for (int j = a; j < A; j += LANES) out_logits[(long long)t * A + j] = row[net.io[4] + j];
     if (a == 0) { out_value[t] = value; out_reward[t] = reward; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Whole searches level by level (networks too wide for a tile of trees in LDS, or more than 16 actions): per
+// simulation one launch per network level plus one tree launch, for a RANGE of trees [row_first, row_first + 32 *
+// gridDim.y) so that several ranges can run on streams of their own, one range's matrix work beside another's tree work.
+
+// One level for a range of trees, inputs already in `acts` (the tree kernel below stages them).  A wave asks for ALL
+// weights of its column tile first (<= MZ_LVL_KB blocks, a fixed number of buffer loads: blocks it does not have are
+// addressed out of range and cost no memory access), then the block copies its trees' input columns into LDS, so the
+// weights' latency hides behind the copy's.  Same k order per output as mfma_tile.
+template <int KB>
+__global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet net, const int32_t *desc, float *acts,
+                                                                      int row_first, int level)
+{
+    static_assert(KB == MZ_WPF || KB == 2 * MZ_WPF, "one or two rounds of weight blocks");
+#ifdef MZ_STAMPS
+    long long kst_ = clock64();
+    const int lin_ = blockIdx.y * gridDim.x + blockIdx.x;
+    const int slot_ = (threadIdx.x == 0 && lin_ < 256 && level < 2) ? level * 256 + lin_ : -1;
+#endif
+    constexpr int PT = MZ_LVL_WAVES * 64 / 32;  // threads that copy one tree's inputs
+    extern __shared__ __align__(16) float tile[];  // [32][ts]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // everything the block needs to know in one descriptor (MZ_LVL_DESC ints, see mz_set_network_mfma): one round
+    // trip to memory between the launch and the first weight load
+    const int32_t *q = desc + MZ_LVL_DESC * blockIdx.x;
+    const int KK = q[0], ts = KK + 4, in_off = q[1];
+    const int t0 = row_first + blockIdx.y * 32;
+    const bool active = wave < q[7];
+    const int32_t *qw = q + 10 + 3 * (active ? wave : 0);
+    const int w_off = qw[0], nkb = active ? qw[1] : 0;
+    const NetBufs nb = net_bufs(net);
+    float4 wa[MZ_WPF], wb[MZ_WPF];
+    int ka[MZ_WPF], kb[MZ_WPF];
+#pragma unroll
+    for (int i = 0; i < MZ_WPF; i++)
+        wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, i < nkb ? lane * 16 + i * 1024 : 0x7ffffff0, w_off, 0));
+    if constexpr (KB > MZ_WPF) {
+#pragma unroll
+        for (int i = 0; i < MZ_WPF; i++) {
+            const int k = MZ_WPF + i;
+            wb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, k < nkb ? lane * 16 + k * 1024 : 0x7ffffff0, w_off, 0));
+        }
+    }
+    if (q[9]) {   // every column tile of the block multiplies input blocks 0, 1, 2, ...: no index list to fetch
+#pragma unroll
+        for (int i = 0; i < MZ_WPF; i++) { ka[i] = i; kb[i] = MZ_WPF + i; }
+    } else {
+        const int32_t *kx = net.kidx + qw[2];
+#pragma unroll
+        for (int i = 0; i < MZ_WPF; i++) {
+            ka[i] = i < nkb ? kx[i] : 0;
+            kb[i] = (KB > MZ_WPF && MZ_WPF + i < nkb) ? kx[MZ_WPF + i] : 0;
+        }
+    }
+    const int col = (q[8] + (active ? wave : 0)) * 16 + (lane & 15), N = q[2];
+    const float bias = (active && col < N) ? net.bias[q[6] + col] : 0.0f;
+    MZ_SSTAMP(slot_, 0)
+    {
+        const int i = tid / PT, part = tid % PT;
+        const float4 *src = reinterpret_cast<const float4 *>(acts + (long long)(t0 + i) * net.stride + in_off);
+        float4 *d4 = reinterpret_cast<float4 *>(tile + i * ts);
+        for (int j = part; j < KK / 4; j += PT) d4[j] = src[j];   // rows past the batch exist in `acts` (zero)
+    }
+    MZ_SSTAMP(slot_, 1)
+    __syncthreads();
+    MZ_SSTAMP(slot_, 2)
+    if (!active) return;
+    const float *a0 = tile + (lane & 15) * ts + (lane >> 4) * 4, *a1 = a0 + 16 * ts;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    mfma_round<2>(nkb < MZ_WPF ? nkb : MZ_WPF, a0, a1, wa, ka, acc0, acc1);
+    if constexpr (KB > MZ_WPF)
+        if (nkb > MZ_WPF) mfma_round<2>(nkb - MZ_WPF, a0, a1, wb, kb, acc0, acc1);
+#ifdef MZ_STAMPS
+    if (acc0[0] == 12345.678f) kst_ += 1;   // the stamp below waits for the matrix instructions
+#endif
+    MZ_SSTAMP(slot_, 3)
+    if (col < N) {
+        const int out_off = q[3], skip_off = q[4], actf = q[5];
+        float *out = acts + (long long)t0 * net.stride;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float *o0 = out + (long long)((lane >> 4) * 4 + j) * net.stride, *o1 = o0 + 16 * (long long)net.stride;
+            float v0 = acc0[j] + bias, v1 = acc1[j] + bias;
+            if (skip_off >= 0) { v0 += o0[skip_off + col]; v1 += o1[skip_off + col]; }
+            o0[out_off + col] = apply_act(v0, actf);
+            o1[out_off + col] = apply_act(v1, actf);
+        }
+    }
+}
+
+// The network inputs of every tree's pending selection into its row of `acts` (once per search, after the first
+// selection; later selections are staged by k_leaf_backup_select).
+__global__ __launch_bounds__(256) void k_stage_inputs(Dev d, MfmaNet net, float *acts)
+{
+    const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
+    if (t >= d.B) return;
+    const int parent = d.sel_parent[t], action = d.sel_action[t];
+    tile_stage_inputs<64>(net, acts + (long long)t * net.stride, d.hidden + ((long long)t * d.L.N + parent) * net.io[6], action, a);
+}
+
+// tile_epilogue<64, 64> for one ungrouped hidden state of at most 64 * NH floats and supports of 65 .. 64 * NE bins, with
+// the row in global memory: every value the epilogue needs is asked for up front (one trip to memory instead of one
+// per reduction pass) and each exponential is taken once.  Same operations in the same order per lane as
+// support_to_scalar2<64> / minmax_to<64>, hence the same bits.
+template <int NE, int NH>
+__device__ __forceinline__ void leaf_epilogue_regs(const MfmaNet &net, const float *row, int a, float *hidden_dst,
+                                                    double *value, double *reward)
+{
+    const int H = net.io[6], n = net.io[9], L = (n - 1) / 2;
+    const float *lgA = row + net.io[5], *lgB = row + net.io[3], *raw = row + net.io[2];
+    float vA[NE], vB[NE], h[NH];
+#pragma unroll
+    for (int k = 0; k < NE; k++) { const int i = a + 64 * k, ii = i < n ? i : 0; vA[k] = lgA[ii]; vB[k] = lgB[ii]; }
+#pragma unroll
+    for (int k = 0; k < NH; k++) { const int i = a + 64 * k; h[k] = raw[i < H ? i : 0]; }
+    const float ninf = -__builtin_huge_valf();
+    float mA = ninf, mB = ninf;
+#pragma unroll
+    for (int k = 0; k < NE; k++)
+        if (a + 64 * k < n) { mA = vA[k] > mA ? vA[k] : mA; mB = vB[k] > mB ? vB[k] : mB; }
+    auto fmaxl = [](float x, float y) { return y > x ? y : x; };
+    auto fminl = [](float x, float y) { return y < x ? y : x; };
+    auto faddl = [](float x, float y) { return x + y; };
+    auto daddl = [](double x, double y) { return x + y; };
+    mA = wave_reduce(mA, ninf, fmaxl); mB = wave_reduce(mB, ninf, fmaxl);
+    float sA = 0.0f, sB = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NE; k++)
+        if (a + 64 * k < n) { vA[k] = expf(vA[k] - mA); vB[k] = expf(vB[k] - mB); sA += vA[k]; sB += vB[k]; }
+    sA = wave_reduce(sA, 0.0f, faddl); sB = wave_reduce(sB, 0.0f, faddl);
+    double xA = 0.0, xB = 0.0;
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+        const int i = a + 64 * k;
+        if (i < n) { xA += (double)(vA[k] / sA) * (double)(i - L); xB += (double)(vB[k] / sB) * (double)(i - L); }
+    }
+    xA = wave_reduce(xA, 0.0, daddl); xB = wave_reduce(xB, 0.0, daddl);
+    const double y = inv_value_transform(a == 1 ? xB : xA);
+    *value = wave_lane(y, 0);
+    *reward = wave_lane(y, 1);
+    float mn = __builtin_huge_valf(), mx = ninf;
+#pragma unroll
+    for (int k = 0; k < NH; k++)
+        if (a + 64 * k < H) { mn = h[k] < mn ? h[k] : mn; mx = h[k] > mx ? h[k] : mx; }
+    mn = wave_reduce(mn, __builtin_huge_valf(), fminl); mx = wave_reduce(mx, ninf, fmaxl);
+    const float den = (mx - mn) + 1e-5f;
+#pragma unroll
+    for (int k = 0; k < NH; k++)
+        if (a + 64 * k < H) hidden_dst[a + 64 * k] = (h[k] - mn) / den;
+}
+
+// Tree side of one simulation for trees [t_first, t_end), one wave per tree: the epilogue of the leaf evaluation that
+// the level kernels left in `acts` (hidden-state scaling, supports to scalars), expansion + backup, and - unless this
+// was the last simulation - the next simulation's selection, whose network inputs go straight into the tree's row of
+// `acts` for the next level launch.
+template <int RL, bool GUMBEL>
+__global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet net, int t_first, int t_end, int leaf,
+                                                                  float *acts, const double *noise, int noise_max_calls,
+                                                                  int select_next)
+{
+    __shared__ __align__(16) double s_bk[MZ_BLOCK];
+    __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
+    __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
+    const int t = t_first + (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / 64), a = threadIdx.x % 64;
+    const bool on = a < d.L.A;
+    // the pending selection is asked for before the tables are staged: both waits overlap
+    int parent = 0, action = 0, ntp = 0, depth = 0;
+    if (t < t_end) { parent = d.sel_parent[t]; action = d.sel_action[t]; ntp = d.sel_ntp[t]; depth = d.sel_depth[t]; }
+#ifdef MZ_STAMPS
+    long long kst_ = clock64();
+    const int slot_ = (threadIdx.x == 0 && blockIdx.x < 256) ? 512 + blockIdx.x : -1;
+#endif
+    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
+    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
+    if (t >= t_end) return;
+    MZ_SSTAMP(slot_, 0)
+    if (depth < 1 || depth > d.L.S || parent < 0 || parent >= leaf) {
+        if (a == 0) atomicExch(d.err, 1);
+        return;
+    }
+    const int H = net.io[6];
+    float *row = acts + (long long)t * net.stride;
+    float *hid = d.hidden + (long long)t * d.L.N * H;
+    double value, reward;
+    const float lg = on ? row[net.io[4] + a] : 0.0f;
+    if (net.io[9] <= 64) tile_epilogue<64, 16>(net, row, a, hid + (long long)leaf * H, &value, &reward);
+    else if (net.io[9] <= 640 && net.io[10] == 1 && H > 16 && H <= 256 && !net.plane_major)
+        leaf_epilogue_regs<10, 4>(net, row, a, hid + (long long)leaf * H, &value, &reward);
+    else tile_epilogue<64, 64>(net, row, a, hid + (long long)leaf * H, &value, &reward);
+#ifdef MZ_STAMPS
+    if (value == 12345.678 && lg == 3.0f) kst_ += 1;   // the stamp waits for the epilogue's results
+#endif
+    MZ_SSTAMP(slot_, 1)
+    const TreeMem m = tree_mem(d, t);
+    expand_backup<64, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, s_bk + (threadIdx.x / 64) * 64);
+    if (a == 0) d.visit_total[t] += depth + 1;
+    if (!select_next) {
+        if (a == 0) d.sel_depth[t] = -1;
+        return;
+    }
+    __threadfence_block();
+    MZ_SSTAMP(slot_, 2)
+    const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
+    DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
+    uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
+    parent = descend<64, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+    MZ_SSTAMP(slot_, 3)
+    if (a == 0) {
+        if constexpr (!GUMBEL) store_noise_calls(d, t, calls, noise_max_calls);
+        d.sel_parent[t] = parent; d.sel_action[t] = action; d.sel_ntp[t] = ntp; d.sel_depth[t] = depth;
+    }
+    tile_stage_inputs<64>(net, row, hid + (long long)parent * H, action, a);
+#ifdef MZ_STAMPS
+    __threadfence();
+#endif
+    MZ_SSTAMP(slot_, 4)
+#ifdef MZ_STAMPS
+    if (slot_ >= 0) mz_dbg_stamps[slot_ * 8 + 5] = depth;
+#endif
 }
 
 // The whole simulation loop in one launch with leaves evaluated on the matrix cores: per simulation

@@ -169,18 +169,14 @@ class BatchedSelfPlay:
                 prior = eng.root_prepare(lg.reshape(self.B, e.A), e.legal, dirichlet, frac)
                 eng.reset(prior, val.reshape(self.B), hid.reshape(self.B, -1), e.to_play, e.legal, g,
                           tree_id0=self.tree_id0)
-                if self.mode == 'mfma' and e.A <= 16:
-                    eng.search_mfma(noise)   # the whole simulation loop in one launch
-                for _ in range(int(cfg.simulations) if not (self.mode == 'mfma' and e.A <= 16) else 0):
-                    if self.mode == 'mfma':
-                        eng.select(noise, want_hidden=False)
-                        eng.expand_backup_net()
-                    else:
-                        parent, action, phid = eng.select(noise)
-                        enc = torch.nn.functional.one_hot(action.cpu().long(), net.action_size if hasattr(net, 'action_size') else e.A).float()
-                        l2, nh, v2, r2 = net.recurrent_inference(phid.cpu().reshape(self.B, *hid.shape[1:]), enc)
-                        eng.expand_backup(l2.reshape(self.B, e.A), v2.reshape(self.B), r2.reshape(self.B),
-                                          nh.reshape(self.B, -1))
+                if self.mode == 'mfma':
+                    eng.search_mfma(noise)   # the whole simulation loop in one call
+                for _ in range(int(cfg.simulations) if self.mode != 'mfma' else 0):
+                    parent, action, phid = eng.select(noise)
+                    enc = torch.nn.functional.one_hot(action.cpu().long(), net.action_size if hasattr(net, 'action_size') else e.A).float()
+                    l2, nh, v2, r2 = net.recurrent_inference(phid.cpu().reshape(self.B, *hid.shape[1:]), enc)
+                    eng.expand_backup(l2.reshape(self.B, e.A), v2.reshape(self.B), r2.reshape(self.B),
+                                      nh.reshape(self.B, -1))
         if u is None and not self.gumbel:
             if root_noise is not None or getattr(self, '_u_next', None) is None:
                 self._root_noise()   # advances the block that also holds the sampling uniforms

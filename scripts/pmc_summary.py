@@ -4,13 +4,18 @@ dominant kernel.  Usage: python scripts/pmc_summary.py <tag> <round-name>"""
 import csv, glob, json, os, shutil, sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
-DOMINANT = {'cfg2': 'k_search_reg', 'cfg4s': 'k_search_reg', 'cfg3h': 'k_search_hash'}
+DOMINANT = {'cfg3': 'k_search_gcache', 'cfg2': 'k_search_reg', 'cfg4s': 'k_search_reg', 'cfg3h': 'k_search_hash',
+            'cfg5': 'k_net_level_rows'}
 NOTE = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py (5 steps), mean over the '
         'kernel launches; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (counters are in KiB; gfx950 tallies 128-byte '
         'read requests at 64 bytes).  Calibrated on this access pattern with k_to_act of the same runs: 8192 root '
         'records of 128 B plus 128 KB of per-tree inputs = 1.15 MB read, FETCH_SIZE 573 KB; 360 KB written, '
         'WRITE_SIZE 352 KB')
 traffic, raw = {}, {}
+st = glob.glob(f'gpurun_out/{tag}_stats_default/**/*kernel_stats.csv', recursive=True)
+if st:
+    shutil.copy(st[0], f'profiles/{rnd}_default_command_kernel_stats.csv')
+    shutil.copy(f'gpurun_out/{tag}_stats_default.json', f'profiles/{rnd}_default_command_bench_under_rocprof.json')
 for w, kern in DOMINANT.items():
     st = glob.glob(f'gpurun_out/{tag}_stats_{w}/**/*kernel_stats.csv', recursive=True)
     if st:

@@ -7,7 +7,11 @@ tag=${1:-prof}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-for w in cfg2 cfg4s cfg3h; do
+# the default command (the headline workload, cfg3), exactly as the driver runs it
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_default -o r --output-format csv -- \
+    python3 $root/bench.py > $out/${tag}_stats_default.json 2> $out/${tag}_stats_default.err
+echo "profiled the default command"
+for w in ${WORKLOADS:-cfg3 cfg2 cfg4s cfg3h cfg5}; do
     timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_$w -o r --output-format csv -- \
         python3 $root/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_stats_$w.json 2> $out/${tag}_stats_$w.err
     for c in FETCH_SIZE WRITE_SIZE; do

@@ -1,5 +1,6 @@
 """GPU: the Atari-shaped configuration (hidden 256, 601-bin supports, 18 actions, 200 simulations, PUCT) with its REAL
-network leg, both matrix-core paths (activation tiles in LDS; level by level through global memory), against the CPU
+network leg on every matrix-core path (activation tiles in LDS; level by level through global memory, one simulation
+per call; the whole search level by level in one call), against the CPU
 checker - random-init network (shallow trees) and a peaked-prior variant (deep trees).
 
 Network outputs of two float32 evaluators differ in the last bits, and a PUCT search amplifies a last-bit difference
@@ -39,11 +40,12 @@ def _network(peaked):
 
 
 @pytest.mark.parametrize('peaked', [False, True])
-@pytest.mark.parametrize('path', ['tile', 'level'])
+@pytest.mark.parametrize('path', ['tile', 'level', 'search'])
 def test_cfg5_network_leg_against_checker(path, peaked, monkeypatch):
     from muzero_amd.engine import SearchEngine
     from oracle import oracle as orc
-    monkeypatch.setenv('MZ_NET_PATH', path)
+    if path != 'search':
+        monkeypatch.setenv('MZ_NET_PATH', path)
     A, S, B, seed, tid0 = 18, 200, 256, 4, 1000
     net = _network(peaked)
     packed = pack_network(net)
@@ -63,9 +65,12 @@ def test_cfg5_network_leg_against_checker(path, peaked, monkeypatch):
     eng.set_network_mfma(*pack_network_mfma(gnet))
     prior = eng.root_prepare(logits, legal, di, 0.25)
     eng.reset(prior, value, hidden, tp, legal, tree_id0=tid0)
-    eng.select(want_hidden=False)
-    for _ in range(S):
-        eng.expand_backup_net(select_next=True)
+    if path == 'search':
+        eng.search_mfma()     # 18 actions: the whole search runs level by level
+    else:
+        eng.select(want_hidden=False)
+        for _ in range(S):
+            eng.expand_backup_net(select_next=True)
     action, root_value, probs, _ = eng.to_act(0.0)
     nv, _ = eng.stats()
     nv = nv.cpu().numpy()
@@ -98,3 +103,47 @@ def test_cfg5_network_leg_against_checker(path, peaked, monkeypatch):
     # support values up to 300 taken with float32 probabilities (eps 6e-8), which bounds two float32 evaluators'
     # agreement at about 300 * 6e-8 * a few = 5e-5 - observed: 1.2e-5
     assert worst['logits'] <= 1e-5 and worst['hidden'] <= 1e-4 and worst['value'] <= 5e-5 and worst['reward'] <= 5e-5
+
+
+def test_whole_search_by_level_is_the_stepped_search(monkeypatch):
+    """The level-by-level whole search builds, bit for bit, the trees of the one-call-per-simulation path through the
+    per-level kernels (same k order per output, same epilogue lanes, same tree code), also when an engine is reset and
+    searched again."""
+    from muzero_amd.engine import SearchEngine
+    A, S, B, seed = 18, 60, 200, 9       # 200 trees: a last row tile that is not full
+    net = _network(True)
+    gnet = MuZeroNetwork(WIDE, net.state_dict()).to('cuda')
+    rng = np.random.default_rng(3)
+    cfg = make_config(False, A, S, 1, 0.997)
+    obs = torch.as_tensor(rng.standard_normal((B, 128)).astype(np.float32), device='cuda')
+    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    di = rng.dirichlet([0.25] * A, size=B)
+    with torch.no_grad():
+        logits, hidden, value = gnet.initial_flat(obs)
+
+    def run(mode):
+        monkeypatch.setenv('MZ_NET_PATH', 'level')
+        eng = SearchEngine(cfg, net.H, B, seed=seed)
+        eng.set_network_mfma(*pack_network_mfma(gnet))
+        prior = eng.root_prepare(logits, legal, di, 0.25)
+        eng.reset(prior, value, hidden, tp, legal, tree_id0=0)
+        if mode == 'search':
+            for rep in range(2):
+                if rep:
+                    eng.reset(prior, value, hidden, tp, legal, tree_id0=0)
+                eng.search_mfma()
+        else:
+            eng.select(want_hidden=False)
+            for _ in range(S):
+                eng.expand_backup_net(select_next=True)
+        eng.check()
+        trees = [eng.export_tree(b) for b in range(0, B, 7)]
+        nv, _ = eng.stats()
+        eng.close()
+        return trees, nv.cpu().numpy()
+
+    ref, nv_ref = run('step')
+    got, nv = run('search')
+    np.testing.assert_array_equal(nv, nv_ref)
+    for x, y in zip(got, ref):
+        assert_tree_equal(SimpleNamespace(**x), y, hidden=True)
