@@ -76,7 +76,7 @@ WORKLOADS = {
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3s': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, one leaf-evaluation launch + one backup/selection launch per simulation (comparison)', True, 9, 100, 2, 1, 16384, 'mfma_step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
-    'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), whole search in one call: level-by-level leaf evaluation on the matrix cores, tree ranges on streams of their own (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma'),
+    'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), whole search in one call: per simulation one matrix-core launch per network level and one tree launch (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma'),
     'cfg5s': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), one call per simulation: a launch per network level, epilogue, backup + next selection (comparison)', False, 18, 200, 1, 0.997, 1024, 'mfma_step'),
     'cfg5t': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), leaves evaluated by torch ops (comparison)', False, 18, 200, 1, 0.997, 1024, 'step5'),
     'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
@@ -365,11 +365,11 @@ def main():
         'recording': ({'where': 'device move log, written by k_act_env', 'games_recorded_rank0': games_recorded,
                        'moves_recorded_rank0': B * n_steps} if leaf == 'selfplay' else None),
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation and tree range' if A > 16 else 'k_search_mfma'), 'mfma_step': 'k_net_step+k_backup_select', 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
+                                'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation and tree range' if A > 16 else 'k_search_mfma'), 'mfma_step': ('k_net_level x levels + k_net_epilogue + k_backup_select, per simulation' if A > 16 else 'k_net_step+k_backup_select'), 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
-                     'limiter': LIMITER.get(leaf, LIMITER['tree'])},
+                     'limiter': LIMITER['mfma_levels'] if (leaf in ('mfma', 'mfma_step') and A > 16) else LIMITER.get(leaf, LIMITER['tree'])},
     }
 
     if leaf in ('mfma', 'mfma_step') and leaf_macs is not None:
@@ -393,8 +393,13 @@ LIMITER = {
     'tree': 'not HBM: the shader-sequencer counters show the large-batch tree kernels at 70-85% of the VALU issue rate '
             '(float64 arithmetic in the reference\'s operation order); small batches are one wave per tree, bound by the '
             'latency of ~1000 dependent instructions per simulation',
-    'mfma': 'per simulation a block alternates between the descent (dependent record reads, one per tree level), the '
-            'float32 matrix-core network of its tile and the float64 backup; neither HBM nor the matrix pipes saturate',
+    'mfma': 'per simulation a 32-tree block walks a cached decision table in LDS, runs the float32 matrix-core network of its '
+            'tile (block-sparse weights streamed from L2), then the float64 epilogue, backup and re-decision of the path '
+            'nodes; the shader-sequencer counters show waves parked on waits 46% and stalled on issue 26% of their cycles: '
+            'neither HBM (measured traffic 1.6 TB/s) nor the matrix pipes (17% busy) saturate',
+    'mfma_levels': 'a chain of three launches per simulation over only 1024 trees: every launch is bound by its own start-up, '
+                   'memory round trips and drain (matrix instructions are 3.3 of a level launch\'s 13.7 us), and the chain '
+                   'is serial by construction (the next selection needs this backup)',
 }
 
 

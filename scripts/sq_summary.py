@@ -5,7 +5,7 @@ import csv, glob, sys
 from collections import defaultdict
 
 tag, rnd = sys.argv[1], sys.argv[2]
-DOMINANT = {'cfg2': 'k_search_reg', 'cfg4s': 'k_search_reg', 'cfg3h': 'k_search_hash'}
+DOMINANT = {'cfg3': 'k_search_gcache', 'cfg2': 'k_search_reg', 'cfg4s': 'k_search_reg', 'cfg3h': 'k_search_hash'}
 lines = ['rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS',
          '(scripts/profile_sq.sh; bench.py --steps 3 --warmup 1; mean per launch of the dominant kernel; SQ_WAVE_CYCLES counts units of 4 clocks)', '']
 for w, kern in DOMINANT.items():
