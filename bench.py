@@ -1,6 +1,6 @@
 """Benchmark of the batched MCTS search (BASELINE.json metric: MCTS simulations/sec).
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3h|cfg3s|cfg3t|cfg4|cfg4s|cfg5|cfg5h|cfg5s|cfg5t]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3h|cfg3s|cfg3t|cfg4|cfg4s|cfg5|cfg5d|cfg5h|cfg5s|cfg5t]
 
 One process per GPU.  Under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (torchrun) the process is
 one rank; started plainly with --gpus N > 1 it starts the N ranks itself, as fresh child processes, before
@@ -77,6 +77,7 @@ WORKLOADS = {
     'cfg3s': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, one leaf-evaluation launch + one backup/selection launch per simulation (comparison)', True, 9, 100, 2, 1, 16384, 'mfma_step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
     'cfg5': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256, 18 actions, 601-bin supports), whole search in one call: per simulation one matrix-core launch per network level and one tree launch (BASELINE configs[4] per-GPU shard)', False, 18, 200, 1, 0.997, 1024, 'mfma'),
+    'cfg5d': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden-256 MLP with a peaked policy head (deep trees), whole search in one call', False, 18, 200, 1, 0.997, 1024, 'mfma'),
     'cfg5s': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), one call per simulation: a launch per network level, epilogue, backup + next selection (comparison)', False, 18, 200, 1, 0.997, 1024, 'mfma_step'),
     'cfg5t': ('Atari-shaped 1024 trees x 200 sims PUCT, random-init MLP (hidden 256), leaves evaluated by torch ops (comparison)', False, 18, 200, 1, 0.997, 1024, 'step5'),
     'cfg5h': ('Atari-shaped 1024 trees x 200 sims PUCT, hidden 256, 18 actions, synthetic hash network', False, 18, 200, 1, 0.997, 1024, 'hash'),
@@ -94,7 +95,7 @@ def algorithmic_bytes(node_visits_total, B, S, A, H, gumbel):
 
 
 DEFAULT_STEPS = {'cfg1': 200, 'cfg2': 2000, 'cfg3': 100, 'cfg3h': 200, 'cfg3t': 3, 'cfg3s': 20, 'cfg4': 500, 'cfg4s': 500,
-                 'cfg5': 50, 'cfg5s': 20, 'cfg5h': 200, 'cfg5t': 5}
+                 'cfg5': 50, 'cfg5d': 50, 'cfg5s': 20, 'cfg5h': 200, 'cfg5t': 5}
 MIN_TIMED_S = 1.0     # repeat the block of K steps until this much timed work has accumulated
 MAX_BLOCKS = 200
 
@@ -165,6 +166,9 @@ def main():
     from muzero_amd import hashnet
 
     desc, gumbel, A, S, players, gamma, B, leaf = WORKLOADS[args.workload]
+    if os.environ.get('MZ_BENCH_TREES'):   # experiments only: another batch size (the line's config says so)
+        B = int(os.environ['MZ_BENCH_TREES'])
+        desc += f' [experiment: {B} trees]'
     leaf_macs = None
     cfg = search_config(gumbel, A, S, players, gamma)
     rng = np.random.default_rng(1 + rank)
@@ -205,7 +209,12 @@ def main():
         obs = torch.as_tensor(rng.uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32), device=dev)
     elif leaf in ('mfma', 'mfma_step', 'step5') and A == 18:
         from muzero_amd.packing import pack_network_mfma
-        net = MuZeroNetwork(atari_like_net_config(), seed=0).to(dev)
+        net = MuZeroNetwork(atari_like_net_config(), seed=0)
+        if args.workload == 'cfg5d':   # one action preferred by a wide margin: searches run down long chains
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            sd[sorted(k for k in sd if 'policy_network' in k and k.endswith('bias'))[-1]][7] += 6.0
+            net = MuZeroNetwork(atari_like_net_config(), sd)
+        net = net.to(dev)
         H = net.H
         eng = SearchEngine(cfg, H, B, seed=0, lanes_per_tree=args.lanes)
         pm_io = pack_network_mfma(net)

@@ -13,6 +13,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
+from . import noise as _noise
 from .mcts.mcts import MCTS
 
 
@@ -23,6 +24,7 @@ class BatchedReanalyser:
         self.target_network = target_network
         self.mcts = MCTS(config)
         self.seed = seed
+        self.calls = 0             # batches searched so far: each gets tie-break uniforms of its own
 
     def set_weights(self, network) -> None:
         """Target-network refresh (reanalyse.py:38-42); the cadence is the caller's."""
@@ -51,8 +53,10 @@ class BatchedReanalyser:
                 values = self.target_network.initial_inference(torch.as_tensor(obs, dtype=torch.float32))[2]
             values = np.asarray(values.detach().cpu().numpy(), dtype=np.float64).reshape(B)
         _, root_values, probs = self.mcts.search_batch(self.target_network, obs, legal, np.asarray(to_play), 0,
-                                                       action_encoder=self.game.action_encoder, seed=self.seed,
+                                                       action_encoder=self.game.action_encoder,
+                                                       seed=_noise.move_seed(self.seed, self.calls),
                                                        tree_id0=tree_id0)
+        self.calls += 1
         out, k = [], 0
         for h in histories:
             n = len(h)
