@@ -12,7 +12,12 @@ from muzero_amd.packing import pack_network_mfma
 
 B, S, A = 1024, int(os.environ.get('SIMS', 40)), 18
 cfg = bench.search_config(False, A, S, 1, 0.997)
-net = MuZeroNetwork(bench.atari_like_net_config(), seed=0).to('cuda')
+net = MuZeroNetwork(bench.atari_like_net_config(), seed=0)
+if os.environ.get('PEAKED'):   # deep trees: one action preferred by a wide margin
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd[sorted(k for k in sd if 'policy_network' in k and k.endswith('bias'))[-1]][7] += 6.0
+    net = MuZeroNetwork(bench.atari_like_net_config(), sd)
+net = net.to('cuda')
 eng = SearchEngine(cfg, net.H, B, seed=0)
 eng.set_network_mfma(*pack_network_mfma(net))
 rng = np.random.default_rng(1)

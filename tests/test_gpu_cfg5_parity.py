@@ -105,7 +105,8 @@ def test_cfg5_network_leg_against_checker(path, peaked, monkeypatch):
     assert worst['logits'] <= 1e-5 and worst['hidden'] <= 1e-4 and worst['value'] <= 5e-5 and worst['reward'] <= 5e-5
 
 
-def test_whole_search_by_level_is_the_stepped_search(monkeypatch):
+@pytest.mark.parametrize('gumbel', [False, True])
+def test_whole_search_by_level_is_the_stepped_search(gumbel, monkeypatch):
     """The level-by-level whole search builds, bit for bit, the trees of the one-call-per-simulation path through the
     per-level kernels (same k order per output, same epilogue lanes, same tree code), also when an engine is reset and
     searched again."""
@@ -114,10 +115,11 @@ def test_whole_search_by_level_is_the_stepped_search(monkeypatch):
     net = _network(True)
     gnet = MuZeroNetwork(WIDE, net.state_dict()).to('cuda')
     rng = np.random.default_rng(3)
-    cfg = make_config(False, A, S, 1, 0.997)
+    cfg = make_config(gumbel, A, S, 1, 0.997)
     obs = torch.as_tensor(rng.standard_normal((B, 128)).astype(np.float32), device='cuda')
     legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
-    di = rng.dirichlet([0.25] * A, size=B)
+    di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
+    g = rng.gumbel(size=(B, A)) if gumbel else None
     with torch.no_grad():
         logits, hidden, value = gnet.initial_flat(obs)
 
@@ -126,11 +128,11 @@ def test_whole_search_by_level_is_the_stepped_search(monkeypatch):
         eng = SearchEngine(cfg, net.H, B, seed=seed)
         eng.set_network_mfma(*pack_network_mfma(gnet))
         prior = eng.root_prepare(logits, legal, di, 0.25)
-        eng.reset(prior, value, hidden, tp, legal, tree_id0=0)
+        eng.reset(prior, value, hidden, tp, legal, g, tree_id0=0)
         if mode == 'search':
             for rep in range(2):
                 if rep:
-                    eng.reset(prior, value, hidden, tp, legal, tree_id0=0)
+                    eng.reset(prior, value, hidden, tp, legal, g, tree_id0=0)
                 eng.search_mfma()
         else:
             eng.select(want_hidden=False)
