@@ -443,7 +443,7 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
     if (net_kind == MZ_NET_MFMA) {
         if (!c->mnet.steps) return fail(MZ_ERR_STATE, "mz_search_run: no network uploaded (call mz_set_network_mfma first)");
         // more than 16 actions, tiles that do not fit in LDS, or too few trees to give every CU a tile: level by level
-        bool by_level = c->rl > 16 || !c->mnet_tile_fits ||
+        bool by_level = c->rl > 16 || !c->mnet.sched_ok8 ||
                         (size_t)c->mnet.stride * 32 * 4 + (size_t)32 * 16 * 8 > 160 * 1024;
         if (const char *e = getenv("MZ_SEARCH_LEVELS")) by_level = by_level || atoi(e) != 0;
         if (by_level) return search_by_level(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
@@ -1003,6 +1003,7 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
         }
     }
     // the two per-wave schedules: job ranges in order, at most 64 jobs per wave, every descriptor inside its buffers
+    bool sched_ok[2] = {false, false};   // an empty schedule = "this tile size is not served" (muzero_amd/packing.py)
     for (int k = 0; k < 2; k++) {
         const int nw = k == 0 ? 8 : 4;
         const int64_t o_start = sched_h[2 * k], o_desc = sched_h[2 * k + 1];
@@ -1011,6 +1012,7 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
             return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent schedule offsets");
         const int32_t *ws = sched_h + o_start, *wd = sched_h + o_desc;
         const int64_t n_wd = (lim_desc - o_desc) / MZ_DESC_INTS;
+        sched_ok[k] = n_wd > 0;
         int64_t prev = 0;
         for (int w = 0; w < nw; w++) {
             for (int l = 0; l <= n_levels; l++) {
@@ -1070,7 +1072,9 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     c->mnet_level_job0 = job0;
     c->mnet_max_k16 = 1;
     for (int s2 = 0; s2 < n_steps; s2++) c->mnet_max_k16 = std::max(c->mnet_max_k16, (int)steps_h[12 * s2 + 2]);
-    c->mnet_tile_fits = (size_t)stride * 16 * 4 <= 160 * 1024;
+    c->mnet.sched_ok8 = sched_ok[0]; c->mnet.sched_ok4 = sched_ok[1];
+    c->mnet_tile_fits = ((size_t)stride * 16 * 4 <= 160 * 1024 && sched_ok[1]) ||
+                        ((size_t)stride * 32 * 4 <= 160 * 1024 && sched_ok[0]);
     HIPCHK(hipMalloc(&c->mnet_bufs[5], jobs.size() * 4));
     HIPCHK(hipMemcpy(c->mnet_bufs[5], jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->mnet_bufs[9], desc.size() * 4));
@@ -1127,7 +1131,7 @@ static int expand_backup_net_impl(mz_ctx *c, int32_t select_next, const double *
     }
     // 32 trees per block while their activations fit in LDS, else 16; batches that would leave most CUs
     // without a tile (and networks whose tile does not fit at all) go level by level through global memory
-    const int tm = (size_t)c->mnet.stride * 32 * 4 <= 160 * 1024 ? 32 : 16;
+    const int tm = ((size_t)c->mnet.stride * 32 * 4 <= 160 * 1024 && c->mnet.sched_ok8) ? 32 : 16;
     bool by_level = force_by_level || !c->mnet_tile_fits || (c->B + tm - 1) / tm < 128;
     if (const char *e = getenv("MZ_NET_PATH")) by_level = force_by_level || !c->mnet_tile_fits || strcmp(e, "level") == 0;
     if (by_level) {

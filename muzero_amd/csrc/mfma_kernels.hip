@@ -99,7 +99,8 @@ bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm)
     const bool layout = L.prior_f32 && L.A == 9 && L.idx16 && L.rec == GL::rec && L.off_crew == GL::off_crew &&
                         L.off_prior == GL::off_prior && L.off_cvis == GL::off_cvis && L.off_cidx == GL::off_cidx;
     const size_t stat = (size_t)tm * 16 * 8 + (size_t)tm * 9 * 8 + (size_t)tm * 24 + 64;  // the kernel's static arrays
-    return layout && (tm == 32 || tm == 16) && gcache_dynamic_lds(d, net, tm) + stat <= 160 * 1024;
+    const bool sched = tm == 32 ? net.sched_ok8 : net.sched_ok4;
+    return layout && sched && (tm == 32 || tm == 16) && gcache_dynamic_lds(d, net, tm) + stat <= 160 * 1024;
 }
 
 hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims)

@@ -15,6 +15,8 @@ struct MfmaNet {
     const int32_t *wstart8, *wdesc8;  // per-wave schedule of a 32-tree tile (8 waves): job ranges per level and
                                       // MZ_DESC_INTS ints per job, see muzero_amd/packing.py
     const int32_t *wstart4, *wdesc4;  // ... of a 16-tree tile (4 waves)
+    int sched_ok8, sched_ok4;         // 0: the network has no schedule for that tile size (more than 64 jobs for a
+                                      // wave): only the level-by-level kernels serve it
     int w_bytes, b_bytes;             // sizes of wfrag and bias in bytes (bounds of the buffer loads)
     const float *wfrag;
     const float *bias;

@@ -342,7 +342,9 @@ def _schedule(per_level, n_levels, n_waves, may_split):
                 wjobs += [si, ct, mode]
         wstart.append(len(wjobs) // 3)
         if (wstart[-1] - wstart[-1 - n_levels]) > 64:
-            raise ValueError('more than 64 matrix jobs per wave: the network is too wide for the tile-resident kernels')
+            # a wave keeps its job descriptors in one register per field (64 lanes): a network with more jobs gets an
+            # EMPTY schedule for this tile size, which tells the engine to evaluate it level by level instead
+            return [0] * (n_waves * (n_levels + 1)), []
     return wstart, wjobs
 
 

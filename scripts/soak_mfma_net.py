@@ -16,10 +16,10 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-from helpers import make_config
+from helpers import make_config, assert_tree_equal, replay_on_checker
 from muzero_amd.engine import SearchEngine
 from muzero_amd.network import MuZeroNetwork
-from muzero_amd.packing import pack_network_mfma
+from muzero_amd.packing import pack_network, pack_network_mfma
 
 SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -106,6 +106,8 @@ for trial in range(TRIALS):
         a, v, p, _ = eng.to_act(0.0)
         nv, _ = eng.stats()
         results[mode] = (a.cpu().numpy().copy(), v.cpu().numpy().copy(), nv.cpu().numpy().copy())
+        if mode in ('mfma', 'mfma_level') and 'trees' not in results:
+            results['trees'] = [eng.export_tree(b) for b in range(B)]
         eng.close()
     base = results.get('mfma') or results.get('mfma_level')
     if base is None:
@@ -114,7 +116,14 @@ for trial in range(TRIALS):
         continue
     for k in ('mfma_fused', 'mfma_search', 'mfma_level'):
         if k not in results or results[k] is base: continue
-        if k == 'mfma_level' and 2 * L + 1 > 64:
+        # over 16 actions, or when a 32-tree tile of activations does not fit in LDS, the whole search runs level by
+        # level: the very search of the layer-by-layer mode
+        search_by_level = A > 16 or pm.stride * 32 * 4 + 32 * 16 * 8 > 160 * 1024
+        if k == 'mfma_search' and search_by_level and 'mfma_level' in results:
+            if not all(np.array_equal(results['mfma_level'][i], results[k][i]) for i in range(3)):
+                ok = False
+                print('LEVEL MODES DIFFER trial', trial, desc, flush=True)
+        if k in ('mfma_level', 'mfma_search') and 2 * L + 1 > 64 and (k == 'mfma_level' or search_by_level):
             same = (base[0] == results[k][0]).mean() >= 0.97 and (np.abs(base[1] - results[k][1]) < 1e-5).mean() >= 0.97
         else:
             same = all(np.array_equal(base[i], results[k][i]) for i in range(3))
@@ -123,8 +132,36 @@ for trial in range(TRIALS):
             print('MODES DIFFER trial', trial, k, desc, flush=True)
     fa = (base[0] == results['torch'][0]).mean(); fv = (np.abs(base[1] - results['torch'][1]) < 1e-5).mean()
     if fa < 0.95 or fv < 0.95:
-        ok = False
-        print('TORCH DISAGREES trial', trial, 'actions %.3f values %.3f' % (fa, fv), desc, flush=True)
+        # Allowed only with an explanation: given its own leaf outputs the matrix-core search is exactly the checker's,
+        # and every one of those outputs is within tolerance of the checker's dense executor on identical inputs -
+        # then the disagreement is float32 drift along deep chains of recurrent steps, not a defect.
+        from oracle import oracle as orc
+        packed = pack_network(net)
+        dvv = np.abs(base[1] - results['torch'][1])
+        explained = True
+        for b in np.argsort(-dvv)[:8]:
+            t = results['trees'][int(b)]
+            try:
+                o = replay_on_checker(cfg, t, net.H, legal[b], int(tp[b]), seed=trial, tree_id=int(b),
+                                      gumbel_noise=None if g is None else g[b])
+                assert_tree_equal(o, t, hidden=False)
+            except AssertionError as e:
+                explained = False
+                print('   replay differs, tree', int(b), str(e)[:200], flush=True)
+                continue
+            par, act = t['parents'][1:], t['action_from_parent'][1:]
+            lg2, nh2, val2, rew2 = orc.net_recurrent_batch(packed, t['hidden_states'][par].reshape(S, -1), act)
+            tol = 1e-5 if L <= 32 else 5e-5
+            errs = (np.abs(lg2 - t['children_prior_logits'][1:]).max(), np.abs(val2 - t['node_raw_values'][1:]).max(),
+                    np.abs(rew2 - t['children_rewards'][par, act]).max())
+            if not (errs[0] <= 1e-5 and errs[1] <= tol and errs[2] <= tol):
+                explained = False
+                print('   leaf outputs off, tree', int(b), errs, flush=True)
+        ok = ok and explained
+        dv = np.abs(base[1] - results['torch'][1])
+        print('   explained by float32 drift:' if explained else '   NOT explained:', end=' ')
+        print('TORCH DISAGREES trial', trial, 'actions %.3f values %.3f' % (fa, fv), 'largest value difference %.3g, median %.3g,' % (dv.max(), np.median(dv)),
+              'mean leaf depth %.1f' % (base[2].mean() / S - 1), desc, flush=True)
     bad += not ok
-    if trial % 5 == 0: print('trial', trial, desc, 'modes', sorted(results), flush=True)
+    if trial % 5 == 0: print('trial', trial, desc, 'modes', sorted(k for k in results if k != 'trees'), flush=True)
 print('done, failing trials:', bad)

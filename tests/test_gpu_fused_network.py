@@ -10,7 +10,9 @@ import torch
 
 from helpers import make_config, assert_tree_equal, replay_on_checker
 from test_network_lowering import load_net, net_config
-from muzero_amd.packing import pack_network
+from types import SimpleNamespace
+
+from muzero_amd.packing import pack_network, pack_network_mfma
 from muzero_amd.network import MuZeroNetwork
 
 pytestmark = pytest.mark.gpu
@@ -413,3 +415,45 @@ def test_register_tree_edge_shapes(S, B, monkeypatch):
             np.testing.assert_array_equal(t0[k], t1[k], err_msg=k)
     np.testing.assert_array_equal(out[0][2], out[1][2])
     np.testing.assert_array_equal(out[0][3], out[1][3])
+
+
+def test_network_without_a_tile_schedule_is_evaluated_level_by_level():
+    """A board ResNet wide enough that neither tile size of the tile-resident kernels serves it (a 32-tree tile of its
+    activations exceeds LDS, the 16-tree tile would need more than 64 jobs per wave): mz_expand_backup_net goes level
+    by level on its own and agrees with torch-evaluated leaves; the one-call search says what to use instead (a layer
+    of 25 input blocks is wider than its level kernel keeps in registers)."""
+    from muzero_amd.engine import SearchEngine
+    ncfg = SimpleNamespace(network='resnet', observation_dim=[3, 4, 4], n_actions=9, n_stacked_observations=1, blocks=3,
+                           channels=24, reduced_channels_reward=8, reduced_channels_policy=8, reduced_channels_value=8,
+                           resnet_fc_reward_layers=[16], resnet_fc_policy_layers=[16], resnet_fc_value_layers=[16],
+                           downsample=False, support_limit=10)
+    net = MuZeroNetwork(ncfg, seed=3)
+    gnet = MuZeroNetwork(ncfg, net.state_dict()).to('cuda')
+    B, S, A = 70, 12, 9
+    rng = np.random.default_rng(8)
+    cfg = make_config(True, A, S, 2, 1)
+    obs = rng.uniform(-1, 1, size=(B, 3, 4, 4)).astype(np.float32)
+    logits, hidden, value = net.initial_inference(torch.as_tensor(obs))
+    logits, hidden, value = logits.numpy(), hidden.numpy().reshape(B, -1), value.numpy()
+    legal, tp, g = np.ones((B, A)), np.zeros(B, np.int32), rng.gumbel(size=(B, A))
+    results = []
+    for mode in ('net', 'torch'):
+        eng = SearchEngine(cfg, net.H, B, seed=1)
+        eng.set_network_mfma(*pack_network_mfma(net))
+        eng.reset(eng.root_prepare(logits, legal), value, hidden, tp, legal, g)
+        if mode == 'net':
+            with pytest.raises(ValueError, match='step API'):
+                eng.search_mfma()
+        for _ in range(S):
+            parent, action, phid = eng.select()
+            if mode == 'net':
+                eng.expand_backup_net()
+            else:
+                lg, nh, val, rew = gnet.recurrent_flat(phid, gnet.encode_actions(action))
+                eng.expand_backup(lg, val, rew, nh)
+        a, v, _, _ = eng.to_act(0.0)
+        eng.check()
+        results.append((a.cpu().numpy().copy(), v.cpu().numpy().copy()))
+        eng.close()
+    assert (results[0][0] == results[1][0]).mean() >= 0.95
+    assert (np.abs(results[0][1] - results[1][1]) < 1e-5).mean() >= 0.95

@@ -124,3 +124,20 @@ def test_action_plane_smaller_than_action_count_is_rejected():
     cfg.observation_dim = [3, 2, 2]
     with pytest.raises(ValueError):
         MuZeroNetwork(cfg, seed=0)
+
+
+def test_network_with_more_jobs_than_a_wave_holds_gets_no_tile_schedule():
+    """A wave of the tile-resident matrix-core kernels keeps its job descriptors in one register per field, 64 jobs at
+    most: a network that needs more (here 300 column tiles dealt to the 4 waves of a 16-tree tile) gets an EMPTY
+    schedule for that tile size - the engine then evaluates it level by level - instead of an error."""
+    from muzero_amd.packing import pack_network_mfma, DESC_INTS
+    ncfg = SimpleNamespace(network='resnet', observation_dim=[3, 4, 4], n_actions=9, n_stacked_observations=1, blocks=3,
+                           channels=24, reduced_channels_reward=8, reduced_channels_policy=8, reduced_channels_value=8,
+                           resnet_fc_reward_layers=[16], resnet_fc_policy_layers=[16], resnet_fc_value_layers=[16],
+                           downsample=False, support_limit=10)
+    pm, io = pack_network_mfma(MuZeroNetwork(ncfg, seed=0))
+    h = pm.sched[:4]
+    n8, n4 = (h[2] - h[1]) // DESC_INTS, (len(pm.sched) - h[3]) // DESC_INTS
+    assert n8 > 0 and n4 == 0
+    assert not pm.sched[h[2]:h[3]].any()          # job ranges of the empty schedule: all zero
+    assert len(pm.ctinfo) // 3 >= 256             # the column tiles are all there for the level-by-level kernels
