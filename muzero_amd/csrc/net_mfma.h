@@ -510,7 +510,8 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     extern __shared__ __align__(16) float tile[];  // [32][ts]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // everything the block needs to know in one descriptor (MZ_LVL_DESC ints, see mz_set_network_mfma): one round
-    // trip to memory between the launch and the first weight load
+    // trip to memory between the launch and the first weight load (passing the descriptors inside the kernel
+    // arguments instead was measured: 0.7 % on the 1024-tree search, not kept)
     const int32_t *q = desc + MZ_LVL_DESC * blockIdx.x;
     const int KK = q[0], ts = KK + 4, in_off = q[1];
     const int t0 = row_first + blockIdx.y * 32;
@@ -592,16 +593,27 @@ __global__ __launch_bounds__(256) void k_stage_inputs(Dev d, MfmaNet net, float 
 // per reduction pass) and each exponential is taken once.  Same operations in the same order per lane as
 // support_to_scalar2<64> / minmax_to<64>, hence the same bits.
 template <int NE, int NH>
-__device__ __forceinline__ void leaf_epilogue_regs(const MfmaNet &net, const float *row, int a, float *hidden_dst,
+struct LeafRegs { float vA[NE], vB[NE], h[NH]; };
+
+// ... the loads (issued by the caller as early as it knows the row)
+template <int NE, int NH>
+__device__ __forceinline__ void leaf_epilogue_load(const MfmaNet &net, const float *row, int a, LeafRegs<NE, NH> &r)
+{
+    const int H = net.io[6], n = net.io[9];
+    const float *lgA = row + net.io[5], *lgB = row + net.io[3], *raw = row + net.io[2];
+#pragma unroll
+    for (int k = 0; k < NE; k++) { const int i = a + 64 * k, ii = i < n ? i : 0; r.vA[k] = lgA[ii]; r.vB[k] = lgB[ii]; }
+#pragma unroll
+    for (int k = 0; k < NH; k++) { const int i = a + 64 * k; r.h[k] = raw[i < H ? i : 0]; }
+}
+
+// ... and the arithmetic
+template <int NE, int NH>
+__device__ __forceinline__ void leaf_epilogue_regs(const MfmaNet &net, LeafRegs<NE, NH> &r, int a, float *hidden_dst,
                                                     double *value, double *reward)
 {
     const int H = net.io[6], n = net.io[9], L = (n - 1) / 2;
-    const float *lgA = row + net.io[5], *lgB = row + net.io[3], *raw = row + net.io[2];
-    float vA[NE], vB[NE], h[NH];
-#pragma unroll
-    for (int k = 0; k < NE; k++) { const int i = a + 64 * k, ii = i < n ? i : 0; vA[k] = lgA[ii]; vB[k] = lgB[ii]; }
-#pragma unroll
-    for (int k = 0; k < NH; k++) { const int i = a + 64 * k; h[k] = raw[i < H ? i : 0]; }
+    float (&vA)[NE] = r.vA, (&vB)[NE] = r.vB, (&h)[NH] = r.h;
     const float ninf = -__builtin_huge_valf();
     float mA = ninf, mB = ninf;
 #pragma unroll
@@ -654,7 +666,19 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     const bool on = a < d.L.A;
     // the pending selection is asked for before the tables are staged: both waits overlap
     int parent = 0, action = 0, ntp = 0, depth = 0;
-    if (t < t_end) { parent = d.sel_parent[t]; action = d.sel_action[t]; ntp = d.sel_ntp[t]; depth = d.sel_depth[t]; }
+    const int H = net.io[6];
+    const bool live = t < t_end;
+    float *row = acts + (long long)(live ? t : t_first) * net.stride;
+    // long supports, one ungrouped hidden state: the epilogue's values are asked for here as well
+    const bool wide = net.io[9] > 64 && net.io[9] <= 640 && net.io[10] == 1 && H > 16 && H <= 256 && !net.plane_major;
+    LeafRegs<10, 4> lr;
+    float lg = 0.0f;
+    if (live) {
+        parent = d.sel_parent[t]; action = d.sel_action[t]; ntp = d.sel_ntp[t]; depth = d.sel_depth[t];
+        lg = on ? row[net.io[4] + a] : 0.0f;
+        if (wide) leaf_epilogue_load<10, 4>(net, row, a, lr);
+    }
+
 #ifdef MZ_STAMPS
     long long kst_ = clock64();
     const int slot_ = (threadIdx.x == 0 && blockIdx.x < 256) ? 512 + blockIdx.x : -1;
@@ -667,20 +691,16 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
         if (a == 0) atomicExch(d.err, 1);
         return;
     }
-    const int H = net.io[6];
-    float *row = acts + (long long)t * net.stride;
+    const TreeMem m = tree_mem(d, t);
     float *hid = d.hidden + (long long)t * d.L.N * H;
     double value, reward;
-    const float lg = on ? row[net.io[4] + a] : 0.0f;
-    if (net.io[9] <= 64) tile_epilogue<64, 16>(net, row, a, hid + (long long)leaf * H, &value, &reward);
-    else if (net.io[9] <= 640 && net.io[10] == 1 && H > 16 && H <= 256 && !net.plane_major)
-        leaf_epilogue_regs<10, 4>(net, row, a, hid + (long long)leaf * H, &value, &reward);
+    if (wide) leaf_epilogue_regs<10, 4>(net, lr, a, hid + (long long)leaf * H, &value, &reward);
+    else if (net.io[9] <= 64) tile_epilogue<64, 16>(net, row, a, hid + (long long)leaf * H, &value, &reward);
     else tile_epilogue<64, 64>(net, row, a, hid + (long long)leaf * H, &value, &reward);
 #ifdef MZ_STAMPS
     if (value == 12345.678 && lg == 3.0f) kst_ += 1;   // the stamp waits for the epilogue's results
 #endif
     MZ_SSTAMP(slot_, 1)
-    const TreeMem m = tree_mem(d, t);
     expand_backup<64, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, s_bk + (threadIdx.x / 64) * 64);
     if (a == 0) d.visit_total[t] += depth + 1;
     if (!select_next) {
