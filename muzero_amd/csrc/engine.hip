@@ -412,8 +412,6 @@ static int lvl_issue_range(mz_ctx *c, int n_sims, const double *noise, int32_t n
 
 static int search_by_level(mz_ctx *c, int n_sims, const double *noise, int32_t noise_max_calls, hipStream_t stream)
 {
-    if (c->mnet_max_k16 > MZ_LVL_KB)
-        return fail(MZ_ERR_ARG, "mz_search_run: a layer is wider than the level-by-level search serves; use the step API");
     if (!shape_supported(64, c->rl)) return fail(MZ_ERR_ARG, "mz_search_run: unsupported action count");
     int rc = lvl_issue_first(c, noise, noise_max_calls, stream);
     if (rc) return rc;

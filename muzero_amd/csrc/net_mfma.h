@@ -492,10 +492,11 @@ __global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int le
 // simulation one launch per network level plus one tree launch, for a RANGE of trees [row_first, row_first + 32 *
 // gridDim.y) so that several ranges can run on streams of their own, one range's matrix work beside another's tree work.
 
-// One level for a range of trees, inputs already in `acts` (the tree kernel below stages them).  A wave asks for ALL
-// weights of its column tile first (<= MZ_LVL_KB blocks, a fixed number of buffer loads: blocks it does not have are
-// addressed out of range and cost no memory access), then the block copies its trees' input columns into LDS, so the
-// weights' latency hides behind the copy's.  Same k order per output as mfma_tile.
+// One level for a range of trees, inputs already in `acts` (the tree kernel below stages them).  A wave asks for the
+// weights of its column tile first (up to MZ_LVL_KB blocks, a fixed number of buffer loads: blocks it does not have
+// are addressed out of range and cost no memory access; wider layers fetch the rest in rounds later), then the block
+// copies its trees' input columns into LDS, so the weights' latency hides behind the copy's.  Same k order per output
+// as mfma_tile.
 template <int KB>
 __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet net, const int32_t *desc, float *acts,
                                                                       int row_first, int level)
@@ -558,8 +559,19 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     const float *a0 = tile + (lane & 15) * ts + (lane >> 4) * 4, *a1 = a0 + 16 * ts;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     mfma_round<2>(nkb < MZ_WPF ? nkb : MZ_WPF, a0, a1, wa, ka, acc0, acc1);
-    if constexpr (KB > MZ_WPF)
-        if (nkb > MZ_WPF) mfma_round<2>(nkb - MZ_WPF, a0, a1, wb, kb, acc0, acc1);
+    if constexpr (KB > MZ_WPF) {
+        if (nkb > MZ_WPF) mfma_round<2>((nkb < KB ? nkb : KB) - MZ_WPF, a0, a1, wb, kb, acc0, acc1);
+        // layers wider than KB blocks: further rounds, requested here (their latency is exposed)
+        for (int k0 = KB; k0 < nkb; k0 += MZ_WPF) {
+#pragma unroll
+            for (int i = 0; i < MZ_WPF; i++) {
+                const int k = k0 + i;
+                wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, k < nkb ? lane * 16 + k * 1024 : 0x7ffffff0, w_off, 0));
+                ka[i] = k < nkb ? (q[9] ? k : net.kidx[qw[2] + k]) : 0;
+            }
+            mfma_round<2>(nkb - k0 < MZ_WPF ? nkb - k0 : MZ_WPF, a0, a1, wa, ka, acc0, acc1);
+        }
+    }
 #ifdef MZ_STAMPS
     if (acc0[0] == 12345.678f) kst_ += 1;   // the stamp below waits for the matrix instructions
 #endif

@@ -419,9 +419,9 @@ def test_register_tree_edge_shapes(S, B, monkeypatch):
 
 def test_network_without_a_tile_schedule_is_evaluated_level_by_level():
     """A board ResNet wide enough that neither tile size of the tile-resident kernels serves it (a 32-tree tile of its
-    activations exceeds LDS, the 16-tree tile would need more than 64 jobs per wave): mz_expand_backup_net goes level
-    by level on its own and agrees with torch-evaluated leaves; the one-call search says what to use instead (a layer
-    of 25 input blocks is wider than its level kernel keeps in registers)."""
+    activations exceeds LDS, the 16-tree tile would need more than 64 jobs per wave; layers of 25 input blocks, more
+    than a level kernel requests up front): both the one-call search and mz_expand_backup_net go level by level on
+    their own, build the same trees, and agree with torch-evaluated leaves."""
     from muzero_amd.engine import SearchEngine
     ncfg = SimpleNamespace(network='resnet', observation_dim=[3, 4, 4], n_actions=9, n_stacked_observations=1, blocks=3,
                            channels=24, reduced_channels_reward=8, reduced_channels_policy=8, reduced_channels_value=8,
@@ -437,14 +437,13 @@ def test_network_without_a_tile_schedule_is_evaluated_level_by_level():
     logits, hidden, value = logits.numpy(), hidden.numpy().reshape(B, -1), value.numpy()
     legal, tp, g = np.ones((B, A)), np.zeros(B, np.int32), rng.gumbel(size=(B, A))
     results = []
-    for mode in ('net', 'torch'):
+    for mode in ('net', 'torch', 'search'):
         eng = SearchEngine(cfg, net.H, B, seed=1)
         eng.set_network_mfma(*pack_network_mfma(net))
         eng.reset(eng.root_prepare(logits, legal), value, hidden, tp, legal, g)
-        if mode == 'net':
-            with pytest.raises(ValueError, match='step API'):
-                eng.search_mfma()
-        for _ in range(S):
+        if mode == 'search':
+            eng.search_mfma()
+        for _ in range(S if mode != 'search' else 0):
             parent, action, phid = eng.select()
             if mode == 'net':
                 eng.expand_backup_net()
@@ -453,7 +452,10 @@ def test_network_without_a_tile_schedule_is_evaluated_level_by_level():
                 eng.expand_backup(lg, val, rew, nh)
         a, v, _, _ = eng.to_act(0.0)
         eng.check()
-        results.append((a.cpu().numpy().copy(), v.cpu().numpy().copy()))
+        nv, _ = eng.stats()
+        results.append((a.cpu().numpy().copy(), v.cpu().numpy().copy(), nv.cpu().numpy().copy()))
         eng.close()
     assert (results[0][0] == results[1][0]).mean() >= 0.95
     assert (np.abs(results[0][1] - results[1][1]) < 1e-5).mean() >= 0.95
+    for i in range(3):   # one call or one call per simulation: the very same search
+        np.testing.assert_array_equal(results[0][i], results[2][i])
