@@ -54,7 +54,7 @@ struct mz_ctx {
     RootNetDev root;    // representation + prediction programs (mz_set_root_network)
     void *root_bufs[4];
     MfmaNet mnet;       // MFMA-layout network (mz_set_network_mfma)
-    void *mnet_bufs[10];  // steps, per-wave schedules, (unused), wfrag, bias, per-level job table, global activations, ctinfo, kidx, block descriptors of the row-range level kernel
+    void *mnet_bufs[10];  // steps, per-wave schedules, (unused), wfrag, bias, (unused), global activations, ctinfo, kidx, block descriptors of the level kernel
     int mnet_max_k16;                  // widest layer input in blocks of 16 floats
     std::vector<int> mnet_level_job0;  // first block of each level in the job table (+ total at the end)
     bool mnet_tile_fits;               // a 16-tree activation tile fits in LDS (tile-resident kernels usable)
@@ -1035,8 +1035,8 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
             }
         }
     }
-    // job table of the per-level path: blocks of up to MZ_LVL_WAVES column tiles of one step, level by level
-    std::vector<int32_t> jobs, desc;
+    // block descriptors of the level kernel: blocks of up to MZ_LVL_WAVES column tiles of one step, level by level
+    std::vector<int32_t> desc;
     std::vector<int> job0(1, 0);
     for (int l = 0; l < n_levels; l++) {
         for (int s = 0; s < n_steps; s++) {
@@ -1048,8 +1048,7 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
                 return fail(MZ_ERR_ARG, "mz_set_network_mfma: a layer's inputs for 32 trees exceed LDS");
             for (int ct = 0; ct < st[9]; ct += MZ_LVL_WAVES) {
                 const int n = std::min(MZ_LVL_WAVES, st[9] - ct);
-                jobs.push_back(s); jobs.push_back(ct); jobs.push_back(n);
-                // the same block for k_net_level_rows, flattened: step fields + per-wave weight block lists
+                // everything a block needs, flattened: step fields + per-wave weight block lists
                 int32_t q[MZ_LVL_DESC] = {st[2] * 16, st[3], st[1], st[4], st[5], st[6], st[8], n, ct, 1};
                 for (int w = 0; w < n; w++) {
                     if (st[10] + ct + w >= n_jobs) return fail(MZ_ERR_ARG, "mz_set_network_mfma: column tile table too short");
@@ -1062,7 +1061,7 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
                 desc.insert(desc.end(), q, q + MZ_LVL_DESC);
             }
         }
-        job0.push_back((int)jobs.size() / 3);
+        job0.push_back((int)(desc.size() / MZ_LVL_DESC));
     }
     for (int s2 = 0; s2 < n_steps; s2++)
         if (steps_h[12 * s2] < 0 || steps_h[12 * s2] >= n_levels) return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad level");
@@ -1073,8 +1072,6 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     c->mnet.sched_ok8 = sched_ok[0]; c->mnet.sched_ok4 = sched_ok[1];
     c->mnet_tile_fits = ((size_t)stride * 16 * 4 <= 160 * 1024 && sched_ok[1]) ||
                         ((size_t)stride * 32 * 4 <= 160 * 1024 && sched_ok[0]);
-    HIPCHK(hipMalloc(&c->mnet_bufs[5], jobs.size() * 4));
-    HIPCHK(hipMemcpy(c->mnet_bufs[5], jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->mnet_bufs[9], desc.size() * 4));
     HIPCHK(hipMemcpy(c->mnet_bufs[9], desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
     const size_t act_rows = ((size_t)c->cfg.max_batch + 31) / 32 * 32;
@@ -1134,12 +1131,13 @@ static int expand_backup_net_impl(mz_ctx *c, int32_t select_next, const double *
     if (const char *e = getenv("MZ_NET_PATH")) by_level = force_by_level || !c->mnet_tile_fits || strcmp(e, "level") == 0;
     if (by_level) {
         float *acts = stg.acts;
-        const int32_t *jobs = (const int32_t *)c->mnet_bufs[5];
-        const size_t lds = (size_t)(c->mnet_max_k16 * 16 + 4) * 32 * 4;
+        const int32_t *desc = (const int32_t *)c->mnet_bufs[9];
+        launch_stage_inputs((hipStream_t)stream, c->d, c->mnet, acts);   // the pending selection's network inputs
         for (int l = 0; l < c->mnet.n_levels; l++) {
             const int j0 = c->mnet_level_job0[l], nb = c->mnet_level_job0[l + 1] - j0;
             if (nb < 1) continue;
-            HIPCHK(launch_net_level(l == 0, (unsigned)nb, lds, (hipStream_t)stream, c->d, c->mnet, jobs + 3 * j0, acts));
+            HIPCHK(launch_net_level_rows((unsigned)nb, (unsigned)((c->B + 31) / 32), c->mnet_max_k16, (hipStream_t)stream,
+                                         c->mnet, desc + MZ_LVL_DESC * j0, acts, 0, l));
         }
         // a whole wave per tree when the supports or the hidden state are long
         const int ep_lanes = (c->mnet.io[9] > 64 || c->mnet.io[6] / c->mnet.io[10] > 64) ? 64 : 16;

@@ -14,16 +14,6 @@ hipError_t launch_net_step(int tm, hipStream_t st, const Dev &d, const MfmaNet &
     return hipSuccess;
 }
 
-hipError_t launch_net_level(bool first, unsigned n_blocks, size_t lds, hipStream_t st, const Dev &d, const MfmaNet &net,
-                            const int32_t *jobs, float *acts)
-{
-    auto kern = first ? k_net_level<true> : k_net_level<false>;
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_blocks, (unsigned)((d.B + 31) / 32)), dim3(MZ_LVL_WAVES * 64), lds, st, d, net, jobs, acts);
-    return hipSuccess;
-}
-
 void launch_net_epilogue(int lanes, hipStream_t st, const Dev &d, const MfmaNet &net, int leaf, const float *acts,
                          float *logits, double *value, double *reward)
 {

@@ -6,7 +6,7 @@
 #include "device_common.h"
 
 #define MZ_DESC_INTS 13  // ints per scheduled job (muzero_amd/packing.py DESC_INTS)
-#define MZ_LVL_WAVES 8  // column tiles (= waves) per block of the per-level kernel (k_net_level)
+#define MZ_LVL_WAVES 8  // column tiles (= waves) per block of the level kernel (k_net_level_rows)
 
 namespace mz {
 
@@ -34,9 +34,6 @@ hipError_t ensure_dynamic_lds(const void *kern, size_t bytes);
 // k_net_step<tm>: one simulation's leaves, activations of a tm-tree tile in LDS.
 hipError_t launch_net_step(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int leaf, float *logits, double *value,
                            double *reward);
-// k_net_level<first>: one level of the network for all trees, activations in global memory.
-hipError_t launch_net_level(bool first, unsigned n_blocks, size_t lds, hipStream_t st, const Dev &d, const MfmaNet &net,
-                            const int32_t *jobs, float *acts);
 // k_net_epilogue<lanes>: lanes = 64 or 16 per tree.
 void launch_net_epilogue(int lanes, hipStream_t st, const Dev &d, const MfmaNet &net, int leaf, const float *acts,
                          float *logits, double *value, double *reward);
@@ -47,7 +44,8 @@ hipError_t launch_search_mfma(int rl, bool gumbel, hipStream_t st, const Dev &d,
 // kernel is built for this tree layout and fits in LDS with tm-tree tiles.
 bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm);
 hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims);
-// Whole searches level by level over ranges of trees (k_net_level_rows, k_stage_inputs, k_leaf_backup_select).
+// Level by level through global memory: k_stage_inputs, k_net_level_rows (one level for a range of 32-tree tiles),
+// and for whole searches k_leaf_backup_select.
 #define MZ_LVL_DESC 40  // ints per block descriptor of k_net_level_rows: KK, in_off, N, out_off, skip_off, act, bias_off,
                         // n column tiles, first column tile, dense flag, then per wave: weight byte offset, blocks, kidx offset
 static_assert(MZ_LVL_DESC >= 10 + 3 * MZ_LVL_WAVES, "a block descriptor holds three ints per wave after its ten header ints");

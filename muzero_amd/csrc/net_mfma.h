@@ -38,72 +38,10 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
-// One (step, column tile) job for both 16-row halves of the tile.  Lane (r = lane & 15, q = lane >> 4)
-// supplies, for the j-th of four k-steps of a 16-wide k block, A[row r][k = 16*blk + 4q + j] (four
-// consecutive floats of its tree's activations: one 16-byte LDS read) and the matching weight
-// W[col][same k] (one 16-byte global read of the pre-swizzled fragment).
+// Operand layout of a (step, column tile) job.  Lane (r = lane & 15, q = lane >> 4) supplies, for the j-th of four
+// k-steps of a 16-wide k block, A[row r][k = 16*blk + 4q + j] (four consecutive floats of its tree's activations: one
+// 16-byte LDS read) and the matching weight W[col][same k] (one 16-byte global read of the pre-swizzled fragment).
 #define MZ_WPF 10  // weight blocks fetched per round (k blocks of 16; a job with more runs in rounds of this)
-// HALVES = 2: both 16-row halves of the tile from one pass over the weights (two accumulator chains);
-// HALVES = 1: only half `half` (finer jobs, used to even out levels whose tile count does not divide
-// by the number of waves).
-// Inputs are read from `in` (rows `in_stride` floats apart, the step's input at `in_off`), outputs and the
-// optional skip operand live in `out` (rows `out_stride` apart): the same array for a tile that is
-// resident in LDS, an LDS copy of the inputs and the global activation array for the per-level kernel.
-template <int HALVES>
-__device__ __forceinline__ void mfma_tile(const MfmaNet &net, const float *in, int in_stride, int in_off, float *out,
-                                          int out_stride, const int32_t *st, int ct, int half, int lane)
-{
-    const int N = st[1], out_off = st[4], skip_off = st[5], actf = st[6];
-    const int32_t *job = net.ctinfo + 3 * (st[10] + ct);
-    const int nkb = job[2];
-    const float4 *wp = reinterpret_cast<const float4 *>(net.wfrag + job[0]) + lane;
-    const int32_t *kx = net.kidx + job[1];
-    const int row0 = HALVES == 2 ? 0 : half * 16;
-    const float *a0 = in + (row0 + (lane & 15)) * in_stride + in_off + (lane >> 4) * 4;
-    const float *a1 = a0 + 16 * in_stride;
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < nkb; k0 += MZ_WPF) {
-        float4 w[MZ_WPF];
-        int kb[MZ_WPF];
-#pragma unroll
-        for (int i = 0; i < MZ_WPF; i++)
-            if (k0 + i < nkb) { w[i] = wp[(k0 + i) * 64]; kb[i] = kx[k0 + i]; }
-#pragma unroll
-        for (int i = 0; i < MZ_WPF; i++) {
-            if (k0 + i < nkb) {
-                float4 x0 = *reinterpret_cast<const float4 *>(a0 + kb[i] * 16);
-                float4 x1 = {0, 0, 0, 0};
-                if constexpr (HALVES == 2) x1 = *reinterpret_cast<const float4 *>(a1 + kb[i] * 16);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, w[i].x, acc0, 0, 0, 0);
-                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w[i].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, w[i].y, acc0, 0, 0, 0);
-                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w[i].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, w[i].z, acc0, 0, 0, 0);
-                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w[i].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, w[i].w, acc0, 0, 0, 0);
-                if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w[i].w, acc1, 0, 0, 0);
-            }
-        }
-    }
-    // C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + register
-    const int col = ct * 16 + (lane & 15);
-    if (col < N) {
-        const float b = net.bias[st[8] + col];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int r0 = row0 + (lane >> 4) * 4 + j;
-            float *o0 = out + (long long)r0 * out_stride, *o1 = o0 + 16 * (long long)out_stride;
-            float v0 = acc0[j] + b;
-            if (skip_off >= 0) v0 += o0[skip_off + col];
-            o0[out_off + col] = apply_act(v0, actf);
-            if constexpr (HALVES == 2) {
-                float v1 = acc1[j] + b;
-                if (skip_off >= 0) v1 += o1[skip_off + col];
-                o1[out_off + col] = apply_act(v1, actf);
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Tile-resident evaluation (activations of the block's trees in LDS), software-pipelined per wave.
@@ -418,54 +356,11 @@ __global__ __launch_bounds__(TM * 16) void k_net_step(Dev d, MfmaNet net, int le
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Per-level evaluation with the activations in global memory, for batches too small to fill the chip
-// with one tile of trees per block and for networks whose tile does not fit in LDS: the grid covers
-// (blocks of a few column tiles of one step) x (tiles of 32 trees), so a level of a wide network is
-// hundreds of blocks even for a thousand trees.  A block copies its step's input columns of its 32 trees
-// into LDS once; each wave then computes one column tile for all 32 trees.  Same k order per output as
+// Level-by-level evaluation with the activations in global memory, for batches too small to fill the chip with one tile
+// of trees per block, for networks whose tile does not fit in LDS or has no schedule, and for more than 16 actions:
+// the grid covers (blocks of a few column tiles of one step) x (tiles of 32 trees), so a level of a wide network is
+// hundreds of blocks even for a thousand trees (k_stage_inputs, k_net_level_rows below).  Same k order per output as
 // the tile-resident kernels, hence the same results.
-// jobs: int32 [n_blocks][3] = (step, first column tile, number of column tiles <= MZ_LVL_WAVES).
-// FIRST: the level reads the network's inputs, which are taken straight from the trees (hidden state of
-// each tree's selected parent + encoded action, mcts/mcts.py:240-243) instead of `acts`.
-template <bool FIRST>
-__global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level(Dev d, MfmaNet net, const int32_t *jobs, float *acts)
-{
-    constexpr int PT = MZ_LVL_WAVES * 64 / 32;  // threads that copy one tree's inputs
-    extern __shared__ __align__(16) float tile[];  // [32][ts]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t *job = jobs + 3 * blockIdx.x;
-    const int32_t *st = net.steps + 12 * job[0];
-    const int KK = st[2] * 16, ts = KK + 4, in_off = st[3];
-    const int t0 = blockIdx.y * 32, i = tid / PT, part = tid % PT, t = t0 + i;
-    const int H = net.io[6], asz = net.io[8];
-    float *dst = tile + i * ts;
-    if constexpr (FIRST) {
-        int parent = 0, action = -1;
-        const bool live = t < d.B;
-        if (live) { parent = d.sel_parent[t]; action = d.sel_action[t]; }
-        const float *ph = d.hidden + ((long long)(live ? t : 0) * d.L.N + parent) * H;
-        const int rel = in_off - net.io[0];  // the step may read a view that starts inside the input tensor
-        for (int j = part; j < KK; j += PT) {
-            int e = j + rel;
-            float v = 0.0f;
-            if (live) {
-                if (e < H) v = net.plane_major ? ph[(e % net.io[10]) * (H / net.io[10]) + e / net.io[10]] : ph[e];
-                else v = (e - H == action && e < H + asz) ? 1.0f : 0.0f;
-            }
-            dst[j] = v;
-            // later levels may read the inputs too (residual skips): keep them in `acts` as well (the
-            // blocks of this level that share a tree tile write the same values)
-            if (e < H + asz) acts[(long long)t * net.stride + in_off + j] = v;
-        }
-    } else {
-        const float4 *src = reinterpret_cast<const float4 *>(acts + (long long)t * net.stride + in_off);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int j = part; j < KK / 4; j += PT) d4[j] = src[j];   // rows past the batch exist in `acts` (zero)
-    }
-    __syncthreads();
-    if (wave < job[2])
-        mfma_tile<2>(net, tile, ts, 0, acts + (long long)t0 * net.stride, net.stride, st, job[1] + wave, 0, lane);
-}
 
 // Epilogue of the per-level path: one group of LANES (16 or 64) lanes per tree reads its row of `acts`.
 // The reductions are order-insensitive except for the float32 sums of the supports, whose order depends
@@ -496,7 +391,7 @@ __global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int le
 // weights of its column tile first (up to MZ_LVL_KB blocks, a fixed number of buffer loads: blocks it does not have
 // are addressed out of range and cost no memory access; wider layers fetch the rest in rounds later), then the block
 // copies its trees' input columns into LDS, so the weights' latency hides behind the copy's.  Same k order per output
-// as mfma_tile.
+// as tile_job.
 template <int KB>
 __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet net, const int32_t *desc, float *acts,
                                                                       int row_first, int level)
