@@ -1,4 +1,5 @@
 // The matrix-core kernels (net_mfma.h, search_cached.h) and their launch functions, compiled apart from the C ABI layer.
+#include <cstdlib>
 #include "search_cached.h"  // net_mfma.h, dense_net.h, tree_kernels.h
 
 namespace mz {
@@ -52,6 +53,9 @@ hipError_t launch_net_level_rows(unsigned n_jobs, unsigned n_row_tiles, int max_
     auto kern = max_k16 <= MZ_WPF ? k_net_level_rows<MZ_WPF> : k_net_level_rows<2 * MZ_WPF>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
+#ifdef MZ_STAMPS
+    if (const char *e = getenv("MZ_LVL_STOP")) level |= atoi(e) << 8;
+#endif
     hipLaunchKernelGGL(kern, dim3(n_jobs, n_row_tiles), dim3(MZ_LVL_WAVES * 64), lds, st, net, desc, acts, row_first, level);
     return hipSuccess;
 }
