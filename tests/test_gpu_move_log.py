@@ -132,3 +132,33 @@ def test_play_returns_the_games_of_its_window_and_a_full_log_is_refused():
     with pytest.raises(ValueError, match='full'):
         sp.engine.act_env_step(sp.envs.struct, 1.0, sp._u_block[0], sp.out, sp.log.struct, 2)
     sp.engine.close()
+
+
+def test_move_log_arguments_are_checked():
+    """A log shaped for another batch, an incomplete log and bad row counts are refused with MZ_ERR_ARG before anything
+    is launched."""
+    import ctypes as C
+    from muzero_amd.engine import MzMoveLog, lib
+    from muzero_amd.targets import MoveLog
+    sp, cfg, A, shape = _selfplay('cartpole', 16, seed=2)
+    sp.step(1.0)   # creates the trees
+    dev = sp.device
+    other = MoveLog(4, 8, shape, A, dev)          # 8 environments, the engine has 16
+    with pytest.raises(ValueError, match='another batch'):
+        sp.engine.act_env_step(sp.envs.struct, 1.0, sp._u_block[0], sp.out, other.struct, 0)
+    log = MoveLog(4, 16, shape, A, dev)
+    broken = MzMoveLog(4, 16, log.obs_size, A, log.observations.data_ptr(), log.actions.data_ptr(), None,
+                       log.to_plays.data_ptr(), log.root_values.data_ptr(), log.probs.data_ptr(), log.done.data_ptr())
+    with pytest.raises(ValueError, match='incomplete'):
+        sp.engine.act_env_step(sp.envs.struct, 1.0, sp._u_block[0], sp.out, broken, 0)
+    with pytest.raises(ValueError, match='full'):
+        sp.engine.act_env_step(sp.envs.struct, 1.0, sp._u_block[0], sp.out, log.struct, -1)
+    count = torch.zeros(16, dtype=torch.int32, device=dev)
+    assert lib().mz_log_count_games(C.byref(log.struct), 5, C.c_void_p(count.data_ptr()), None) == -1   # more rows than the log has
+    assert lib().mz_log_count_games(C.byref(log.struct), 2, None, None) == -1
+    assert lib().mz_log_list_games(C.byref(log.struct), 2, None, None, None, None) == -1
+    # an empty window lists no games
+    log.rows = 0
+    base, length = log.games()
+    assert base.numel() == 0 and length.numel() == 0
+    sp.engine.close()
