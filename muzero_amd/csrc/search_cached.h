@@ -284,10 +284,17 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     __syncthreads();
 #ifdef MZ_STAMPS
     long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_t = clock64();
+    long long sx[6] = {0, 0, 0, 0, 0, 0}, sx_t = 0;   // finer: walk | epilogue | expansion+backup | fence | (barrier) | decision loads
+#define MZ_XSTAMP(k) { long long n_ = clock64(); sx[k] += n_ - sx_t; sx_t = n_; }
+#define MZ_XSTART() { sx_t = clock64(); }
+#else
+#define MZ_XSTAMP(k)
+#define MZ_XSTART()
 #endif
     for (int s = 0; s < n_sims; s++) {
         const int leaf = first_leaf + s;
         int parent = 0, action = 0, ntp = 0, depth = 0;
+        MZ_XSTART()
         if (live) {
             // MCTS.simulate, mcts/mcts.py:98-114, over the decisions; all lanes of the group read the same words
             int node = 0;
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             parent = node;
             ntp = d.players == 1 ? 0 : (depth & 1);  // starts at player 0, flips once per level (mcts/mcts.py:105,112)
             visited += depth + 1;
+            MZ_XSTAMP(0)
             tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
         }
         MZ_MSTAMP(st_a)
@@ -312,15 +320,29 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
         MZ_MSTAMP(st_b)
         tile_run_levels<TM>(net, nb, act, ts, lane, wf);
         MZ_MSTAMP(st_c)
+        MZ_XSTART()
         if (live) {
             double value, reward;
             tile_epilogue(net, row, a, hid + (long long)leaf * H, &value, &reward);
             const float lg = on ? row[net.io[4] + a] : 0.0f;
+#ifdef MZ_STAMPS
+            if (value == 12345.678 && lg == 7.0f) st_a++;
+            MZ_XSTAMP(1)
+#endif
             expand_backup<16, true>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
             if (a == 0) { s_items[i] = depth + 1; s_depth[i] = depth; }
+#ifdef MZ_STAMPS
+            MZ_XSTAMP(2)
+#endif
         }
         __threadfence_block();   // the records the backup wrote are read by other lanes of the block below
+#ifdef MZ_STAMPS
+        MZ_XSTAMP(3)
+#endif
         __syncthreads();
+#ifdef MZ_STAMPS
+        MZ_XSTAMP(4)
+#endif
         MZ_MSTAMP(st_d)
         // the nodes whose records changed: levels 0..depth-1 of each tree's path, and its new leaf
         {
@@ -343,6 +365,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     if (live && a == 0) {  // diagnostic build only: [walk+stage, barrier wait, network, epilogue+backup, decisions] cycles
         long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
         o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = st_d; o[4] = st_e;
+        for (int k = 0; k < 5; k++) o[5 + k] = sx[k];
     }
 #endif
     if (live && a == 0) d.visit_total[t] += visited;
