@@ -253,9 +253,13 @@ template <int LANES = 16>
 __device__ __forceinline__ void tile_stage_inputs(const MfmaNet &net, float *row, const float *ph, int action, int a)
 {
     const int H = net.io[6], asz = net.io[8];
-    if (net.plane_major) {
+    if (net.plane_major) {   // lane = channel: no index arithmetic per element, consecutive lanes store consecutive floats
         const int C = net.io[10], P = H / C;
-        for (int j = a; j < H; j += LANES) row[net.io[0] + (j % P) * C + j / P] = ph[j];
+        for (int ch = a; ch < C; ch += LANES) {
+            const float *src = ph + ch * P;
+            float *dst = row + net.io[0] + ch;
+            for (int cell = 0; cell < P; cell++) dst[cell * C] = src[cell];
+        }
     } else if ((H & 3) == 0) {
         const float4 *p4 = reinterpret_cast<const float4 *>(ph);
         float4 *r4 = reinterpret_cast<float4 *>(row + net.io[0]);
