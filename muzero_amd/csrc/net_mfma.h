@@ -277,6 +277,12 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBuf
                                                 int lane, WReg &w0)
 {
     int job = 0;
+#ifdef MZ_STAMPS
+    long long lt_ = clock64();   // diagnostic build: cycles per level (jobs, then the wait at its barrier), wave 0 of block 0
+    const bool lw_ = blockIdx.x == 0 && threadIdx.x == 0;
+#endif
+    // (one job ahead: requesting the weights two jobs ahead was measured 4 % slower - the register moves of the
+    // rotation cost more than the latency they hide)
     for (int l = 0; l < net.n_levels; l++) {
         const int lend = __builtin_amdgcn_readlane(ts.lvl_end, l);
         for (; job < lend; job++) {
@@ -285,7 +291,13 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBuf
             tile_job<TM>(net, nb, act, ts, job, lane, w0);
             w0 = w1;
         }
+#ifdef MZ_STAMPS
+        if (lw_ && l < 8) { long long n_ = clock64(); mz_dbg_stamps[7000 + 2 * l] += n_ - lt_; lt_ = n_; }
+#endif
         lds_barrier();
+#ifdef MZ_STAMPS
+        if (lw_ && l < 8) { long long n_ = clock64(); mz_dbg_stamps[7000 + 2 * l + 1] += n_ - lt_; lt_ = n_; }
+#endif
     }
 }
 

@@ -35,3 +35,10 @@ print('shader-clock cycles per simulation, mean over trees: ' +
 if fine is not None:
     print('   of which: walk %.0f (the rest of the first phase stages the inputs)  epilogue %.0f  expansion + backup %.0f  '
           'wait for the stores %.0f  barrier %.0f' % tuple(fine.mean(0) / S))
+lv = np.zeros(8 * 1024, np.int64)
+f = lib().mz_debug_read_net_stamps
+f.argtypes = [C.c_void_p, C.c_int]
+if f(lv.ctypes.data_as(C.c_void_p), lv.size) == 0:
+    x = lv[7000:7016].reshape(8, 2) / (2.0 * S)    # two searches ran above
+    print('   network levels, wave 0 of block 0, cycles per simulation (jobs / wait at the barrier): ' +
+          '  '.join('L%d %.0f/%.0f' % (l, x[l, 0], x[l, 1]) for l in range(8) if x[l].any()))
