@@ -187,6 +187,15 @@ __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, 
     int kb[MZ_WPF];
 #pragma unroll
     for (int i = 0; i < MZ_WPF; i++) kb[i] = (p[i / 4] >> (8 * (i % 4))) & 0xff;
+#ifdef MZ_STAMPS
+    // diagnostic build: cycles of a job before / in / after its matrix instructions, summed per wave of block 0
+    long long jt_ = clock64();
+    const bool jw_ = blockIdx.x == 0 && lane == 0;
+    const int jb_ = 7200 + 8 * (int)(threadIdx.x >> 6);
+#define MZ_JSTAMP(k) if (jw_) { long long n_ = clock64(); mz_dbg_stamps[jb_ + (k)] += n_ - jt_; jt_ = n_; }
+#else
+#define MZ_JSTAMP(k)
+#endif
     const int row0 = mode == 2 ? 16 : 0;
     float *base = act + (row0 + (lane & 15)) * net.stride;
     const float *a0 = base + in_off + (lane >> 4) * 4;
@@ -194,8 +203,13 @@ __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, 
     const bool both = TM == 32 && mode == 0;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     const int n0 = nkb < MZ_WPF ? nkb : MZ_WPF;
+    MZ_JSTAMP(0)
     if (both) mfma_round<2>(n0, a0, a1, first.w, kb, acc0, acc1);
     else mfma_round<1>(n0, a0, a1, first.w, kb, acc0, acc1);
+#ifdef MZ_STAMPS
+    if (acc0[0] == 12345.678f && acc1[3] == 1.0f) jt_++;   // the stamp waits for the results
+#endif
+    MZ_JSTAMP(1)
     if (nkb > MZ_WPF) {  // wide layers: further rounds, loaded here (their latency is exposed)
         const int32_t *kx = net.kidx + sched_get(ts, 9, job);
         for (int k0 = MZ_WPF; k0 < nkb; k0 += MZ_WPF) {
@@ -217,19 +231,36 @@ __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, 
     const int c = lane & 15;
     if (c < ncols) {
         const float b = first.bias;
+        float *o0 = act + (row0 + (lane >> 4) * 4) * net.stride + c, *o1 = o0 + 16 * net.stride;
+        float v0[4], v1[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float *o0 = act + (row0 + (lane >> 4) * 4 + j) * net.stride, *o1 = o0 + 16 * net.stride;
-            float v0 = acc0[j] + b;
-            if (skip_col >= 0) v0 += o0[skip_col + c];
-            o0[out_col + c] = apply_act(v0, actf);
-            if (both) {
-                float v1 = acc1[j] + b;
-                if (skip_col >= 0) v1 += o1[skip_col + c];
-                o1[out_col + c] = apply_act(v1, actf);
+        for (int j = 0; j < 4; j++) { v0[j] = acc0[j] + b; v1[j] = acc1[j] + b; }
+        if (skip_col >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                v0[j] += o0[j * net.stride + skip_col];
+                if (both) v1[j] += o1[j * net.stride + skip_col];
             }
         }
+        // the activation is the job's (wave-uniform): one branch per job, so that a ReLU layer never pays for expm1
+        if (actf == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v0[j] = v0[j] > 0.0f ? v0[j] : 0.0f; v1[j] = v1[j] > 0.0f ? v1[j] : 0.0f; }
+        } else if (actf == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v0[j] = apply_act(v0[j], 2); if (both) v1[j] = apply_act(v1[j], 2); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            o0[j * net.stride + out_col] = v0[j];
+            if (both) o1[j * net.stride + out_col] = v1[j];
+        }
     }
+    MZ_JSTAMP(2)
+#ifdef MZ_STAMPS
+    if (jw_) mz_dbg_stamps[jb_ + 3] += 1;
+#endif
+#undef MZ_JSTAMP
 }
 
 // Shared pieces of the two kernels below.  A block of MZ_NET_NT threads owns a tile of MZ_NET_TM trees;
@@ -281,8 +312,8 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBuf
     long long lt_ = clock64();   // diagnostic build: cycles per level (jobs, then the wait at its barrier), wave 0 of block 0
     const bool lw_ = blockIdx.x == 0 && threadIdx.x == 0;
 #endif
-    // (one job ahead: requesting the weights two jobs ahead was measured 4 % slower - the register moves of the
-    // rotation cost more than the latency they hide)
+    // (one job ahead: requesting the weights two jobs ahead was measured slower, 4 % with a register rotation by
+    // moves and 1 % with three register sets used in turn - weight latency is not what a job waits for)
     for (int l = 0; l < net.n_levels; l++) {
         const int lend = __builtin_amdgcn_readlane(ts.lvl_end, l);
         for (; job < lend; job++) {

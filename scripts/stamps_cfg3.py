@@ -39,6 +39,12 @@ lv = np.zeros(8 * 1024, np.int64)
 f = lib().mz_debug_read_net_stamps
 f.argtypes = [C.c_void_p, C.c_int]
 if f(lv.ctypes.data_as(C.c_void_p), lv.size) == 0:
-    x = lv[7000:7016].reshape(8, 2) / (2.0 * S)    # two searches ran above
-    print('   network levels, wave 0 of block 0, cycles per simulation (jobs / wait at the barrier): ' +
-          '  '.join('L%d %.0f/%.0f' % (l, x[l, 0], x[l, 1]) for l in range(8) if x[l].any()))
+    x = lv[7000:7000 + 8 * 16].reshape(8, 8, 2) / (2.0 * S)    # [wave][level][jobs, barrier wait]; two searches ran above
+    print('   network levels of block 0, cycles per simulation, jobs/wait at the barrier per wave:')
+    for l in range(8):
+        if x[:, l].any():
+            print('     L%d  ' % l + '  '.join('%5.0f/%-5.0f' % (x[w, l, 0], x[w, l, 1]) for w in range(8)))
+    j = lv[7200:7264].reshape(8, 8).astype(np.float64)
+    if j[:, 3].any():
+        print('   jobs of block 0 per wave: count per simulation, cycles per job before / in / after the matrix instructions:')
+        print('     ' + '  '.join('%.1f: %.0f/%.0f/%.0f' % (j[w, 3] / (2 * S), j[w, 0] / j[w, 3], j[w, 1] / j[w, 3], j[w, 2] / j[w, 3]) for w in range(8)))
