@@ -531,15 +531,24 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
 #endif
     if (col < N) {
         const int out_off = q[3], skip_off = q[4], actf = q[5];
-        float *out = acts + (long long)t0 * net.stride;
+        float *o0 = acts + (long long)(t0 + (lane >> 4) * 4) * net.stride + col, *o1 = o0 + 16 * (long long)net.stride;
+        float v0[4], v1[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float *o0 = out + (long long)((lane >> 4) * 4 + j) * net.stride, *o1 = o0 + 16 * (long long)net.stride;
-            float v0 = acc0[j] + bias, v1 = acc1[j] + bias;
-            if (skip_off >= 0) { v0 += o0[skip_off + col]; v1 += o1[skip_off + col]; }
-            o0[out_off + col] = apply_act(v0, actf);
-            o1[out_off + col] = apply_act(v1, actf);
+        for (int j = 0; j < 4; j++) { v0[j] = acc0[j] + bias; v1[j] = acc1[j] + bias; }
+        if (skip_off >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v0[j] += o0[(long long)j * net.stride + skip_off]; v1[j] += o1[(long long)j * net.stride + skip_off]; }
         }
+        // the activation is the block's: one uniform branch, so that linear and ReLU layers never pay for expm1
+        if (actf == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v0[j] = v0[j] > 0.0f ? v0[j] : 0.0f; v1[j] = v1[j] > 0.0f ? v1[j] : 0.0f; }
+        } else if (actf == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v0[j] = apply_act(v0[j], 2); v1[j] = apply_act(v1[j], 2); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o0[(long long)j * net.stride + out_off] = v0[j]; o1[(long long)j * net.stride + out_off] = v1[j]; }
     }
 }
 
