@@ -314,6 +314,8 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBuf
 #endif
     // (one job ahead: requesting the weights two jobs ahead was measured slower, 4 % with a register rotation by
     // moves and 1 % with three register sets used in turn - weight latency is not what a job waits for)
+    // (finishing a job's outputs behind the next job's matrix instructions, with two accumulator sets in turn, was
+    // measured too: 1 % faster in k_net_step, 4 % slower in the whole-search kernels, which it pushes into spilling)
     for (int l = 0; l < net.n_levels; l++) {
         const int lend = __builtin_amdgcn_readlane(ts.lvl_end, l);
         for (; job < lend; job++) {
