@@ -294,6 +294,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     for (int s = 0; s < n_sims; s++) {
         const int leaf = first_leaf + s;
         int parent = 0, action = 0, ntp = 0, depth = 0;
+        BackupPre bp{0, 0, 0, 0, 0.0, 0.0};
         MZ_XSTART()
         if (live) {
             // MCTS.simulate, mcts/mcts.py:98-114, over the decisions; all lanes of the group read the same words
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             visited += depth + 1;
             MZ_XSTAMP(0)
             tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
+            bp = backup_prefetch<16>(d, m, a, depth);   // the path's records travel while the network runs
         }
         MZ_MSTAMP(st_a)
         WReg wf;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             if (value == 12345.678 && lg == 7.0f) st_a++;
             MZ_XSTAMP(1)
 #endif
-            expand_backup<16, true>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk);
+            expand_backup<16, true, true>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk, &bp);
             if (a == 0) { s_items[i] = depth + 1; s_depth[i] = depth; }
 #ifdef MZ_STAMPS
             MZ_XSTAMP(2)

@@ -306,10 +306,32 @@ __device__ __forceinline__ int descend_wide(const Dev &d, const DescendCtx &c, c
 // MCTS.expand (mcts/mcts.py:116-141) for leaf index `leaf`, then MCTS.backward (:143-164) along the
 // recorded path.  `logit` is this lane's prior logit; value/reward are group-uniform.
 // `lds_r`: LANES doubles of LDS owned by this group (staging of the per-level rewards).
-template <int LANES, bool GUMBEL>
+// What the backup reads of the path's first LANES levels (lane i: level i above the leaf).  A kernel that knows the
+// path long before it knows the leaf's value (the leaf is evaluated in between) asks for these early
+// (backup_prefetch) and hands them to expand_backup: the records then travel from HBM while the network runs.
+struct BackupPre {
+    int pk, nv, tp, cvs;
+    double V, r;
+};
+
+template <int LANES>
+__device__ __forceinline__ BackupPre backup_prefetch(const Dev &d, const TreeMem &m, int a, int depth)
+{
+    BackupPre p{0, 0, 0, 0, 0.0, 0.0};
+    if (a < depth) {
+        p.pk = m.path[depth - 1 - a];
+        const RowView pw = view(d, m, p.pk >> 6);
+        p.nv = pw.hdr->visits; p.V = pw.hdr->value; p.tp = pw.hdr->to_play;
+        p.r = pw.crew[p.pk & 63];
+        p.cvs = pw.cvis.get(p.pk & 63);
+    }
+    return p;
+}
+
+template <int LANES, bool GUMBEL, bool PRE = false>
 __device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, int a, bool on, int parent, int action,
                                               int ntp, int depth, int leaf, float logit, double value,
-                                              double reward, double *lds_r)
+                                              double reward, double *lds_r, const BackupPre *pre = nullptr)
 {
     // --- expansion: a fresh record for the leaf, links in the parent
     RowView lf = view(d, m, leaf);
@@ -339,12 +361,19 @@ __device__ __forceinline__ void expand_backup(const Dev &d, const TreeMem &m, in
         double V = 0, r = 0;
         RowView pw;
         if (valid) {
-            int pk = path[depth - 1 - i];
-            p = pk >> 6; pa = pk & 63;
-            pw = view(d, m, p);
-            nv = pw.hdr->visits; V = pw.hdr->value; tp = pw.hdr->to_play;
-            r = i == 0 ? reward : pw.crew[pa];
-            cvs = pw.cvis.get(pa);
+            if (PRE && base == 0) {   // read ahead by the caller, before the expansion wrote the parent's link and
+                p = pre->pk >> 6; pa = pre->pk & 63;   // reward: level 0's reward is the leaf's, not the stored one
+                pw = view(d, m, p);
+                nv = pre->nv; V = pre->V; tp = pre->tp; cvs = pre->cvs;
+                r = i == 0 ? reward : pre->r;
+            } else {
+                int pk = path[depth - 1 - i];
+                p = pk >> 6; pa = pk & 63;
+                pw = view(d, m, p);
+                nv = pw.hdr->visits; V = pw.hdr->value; tp = pw.hdr->to_play;
+                r = i == 0 ? reward : pw.crew[pa];
+                cvs = pw.cvis.get(pa);
+            }
         }
         int cnt = depth - base < LANES ? depth - base : LANES;
         lds_r[a] = r;
