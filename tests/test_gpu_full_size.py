@@ -1,0 +1,157 @@
+"""GPU: the benchmark workloads at their FULL per-GPU sizes, checked against the CPU checker on every tree.
+
+The parity files next to this one work on batches of tens to a thousand trees.  Here the batch is the one the
+throughput figures are quoted on - 16 384 TicTacToe trees x 100 Gumbel simulations (ResNet leaves on the matrix
+cores), 8 192 CartPole trees x 50 PUCT simulations (trees in registers), 1 024 Atari-shaped trees x 200 PUCT
+simulations (level-by-level matrix-core leaves) - so blocks past the first round of the chip, last partial tiles and
+the highest tree offsets are exercised.  Per workload:
+  * every tree: final action, root value and the tree's visit total against the checker's search from the same roots
+    (the share that agrees outright is bounded; float32 leaf outputs differ in the last bits between two evaluators);
+  * every tree that differs (up to a cap) and a fixed sample spread over the batch: exported, and rebuilt bit for bit by
+    the checker from the leaf outputs the GPU search itself stored; those outputs within tolerance of the checker's;
+  * size independence: a sample of the roots searched again as a small batch gives the very same trees, bit for bit
+    (a tree's result may not depend on its position in the batch or on its neighbours)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import bench   # the workloads' network shapes, as benchmarked
+from helpers import make_config, assert_tree_equal, replay_on_checker
+from muzero_amd.network import MuZeroNetwork
+from muzero_amd.packing import pack_network, pack_network_mfma
+
+pytestmark = pytest.mark.gpu
+
+TICTACTOE, CARTPOLE, ATARI_LIKE = bench.tictactoe_net_config(), bench.cartpole_net_config(), bench.atari_like_net_config()
+
+
+def _explain(cfg, packed, trees, idx, legal, tp, seed, tid0, g, tol, hidden_tol):
+    """Trees `idx` (exports in `trees`): the checker rebuilds each from its own stored leaf outputs, and those outputs are
+    within tolerance of the checker's dense executor on the same (parent state, action)."""
+    from oracle import oracle as orc
+    S = cfg.simulations
+    for b in idx:
+        t = trees[b]
+        o = replay_on_checker(cfg, t, packed.H, legal[b], int(tp[b]), seed, tid0 + b, None if g is None else g[b])
+        assert_tree_equal(o, t, hidden=False)
+        par, act = t['parents'][1:], t['action_from_parent'][1:]
+        lg, nh, val, rew = orc.net_recurrent_batch(packed, t['hidden_states'][par].reshape(S, -1), act)
+        assert np.abs(lg - t['children_prior_logits'][1:]).max() <= 1e-5, b
+        assert np.abs(val - t['node_raw_values'][1:]).max() <= tol and np.abs(rew - t['children_rewards'][par, act]).max() <= tol, b
+        if hidden_tol is not None:
+            assert np.abs(nh - t['hidden_states'][1:].reshape(S, -1)).max() <= hidden_tol, b
+
+
+def _full_size(name, net_cfg, gumbel, A, S, players, gamma, B, obs, search, with_mfma, min_share, tol, hidden_tol,
+               monkeypatch, root_tol=None):
+    from muzero_amd.engine import SearchEngine
+    from oracle import oracle as orc
+    seed, tid0 = 6, 3000
+    root_tol = tol if root_tol is None else root_tol
+    net = MuZeroNetwork(net_cfg, seed=0)
+    packed = pack_network(net)
+    gnet = MuZeroNetwork(net_cfg, net.state_dict()).to('cuda')
+    pm_io = pack_network_mfma(gnet) if with_mfma else None
+    rng = np.random.default_rng(B + S)
+    cfg = make_config(gumbel, A, S, players, gamma)
+    with torch.no_grad():
+        logits, hidden, value = gnet.initial_flat(torch.as_tensor(obs, device='cuda'))
+    logits, hidden, value = logits.cpu().numpy(), hidden.cpu().numpy().reshape(B, -1), value.cpu().numpy()
+    legal = np.ones((B, A))
+    if A > 2:
+        for b in range(0, B, 3):
+            legal[b, rng.choice(A, size=rng.integers(1, A - 1), replace=False)] = 0
+    tp = rng.integers(0, players, size=B).astype(np.int32)
+    g = rng.gumbel(size=(B, A)) if gumbel else None
+    di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
+
+    def run(rows, tree_id0):
+        """The searches of roots `rows` as one batch -> (action, root value, visit totals, engine)."""
+        n = len(rows)
+        eng = SearchEngine(cfg, net.H, n, seed=seed)
+        if with_mfma:
+            eng.set_network_mfma(*pm_io)
+        else:
+            eng.set_network(packed)
+        prior = eng.root_prepare(logits[rows], legal[rows], None if di is None else di[rows], 0.25)
+        eng.reset(prior, value[rows], hidden[rows], tp[rows], legal[rows], None if g is None else g[rows], tree_id0=tree_id0)
+        search(eng)
+        eng.check()
+        action, root_value, _, _ = eng.to_act(0.0)
+        nv, _ = eng.stats()
+        return action.cpu().numpy().copy(), root_value.cpu().numpy().copy(), nv.cpu().numpy().copy(), eng
+
+    every = np.arange(B)
+    action, root_value, nv, eng = run(every, tid0)
+    ref = orc.search_batch_net(cfg, packed, logits, hidden, value, legal, tp, dirichlet=di, frac=0.25, gumbel=g, seed=seed,
+                               tree_id0=tid0, n_threads=16)
+    same = (action == ref.action) & (nv == ref.node_visits)
+    close = np.abs(root_value - ref.root_value) < root_tol
+    print(f'{name}: {B} trees x {S} simulations; action and visit total identical {same.mean():.4f}, '
+          f'root value within {root_tol:g} {close.mean():.4f}, mean leaf depth {nv.mean() / S - 1:.2f}')
+    assert same.mean() >= min_share and (close | ~same).mean() >= 0.99
+    assert abs(int(nv.sum()) - int(ref.node_visits.sum())) <= 0.01 * ref.node_visits.sum()
+    legal_pick = legal[every, action] == 1
+    assert legal_pick.all() and np.isfinite(root_value).all()
+    assert (nv >= 2 * S).all() and (nv <= S * (S + 3) // 2).all()      # every leaf at depth >= 1, chains at most
+    # trees that differ (capped) and a sample spread over the whole batch, the first and the last tile included
+    sample = sorted(set(range(0, B, max(1, B // 48))) | {1, 31, 32, B - 33, B - 32, B - 1})
+    differ = np.flatnonzero(~same | (np.abs(root_value - ref.root_value) >= tol))[:48].tolist()
+    trees = {b: eng.export_tree(b) for b in sorted(set(sample) | set(differ))}
+    eng.close()
+    visits = np.stack([trees[b]['children_visits'][0] for b in sample])
+    agree = (visits == ref.root_visits[sample]).all(axis=1)
+    assert (agree | ~same[sample]).all()                                # the cheap signature is not hiding differences
+    _explain(cfg, packed, trees, sorted(trees), legal, tp, seed, tid0, g, tol, hidden_tol)
+    # the sampled roots again, as a small batch at other batch positions: the very same trees
+    rows = np.asarray(sample)
+    if gumbel:      # no per-tree random stream: any tree id will do
+        a2, v2, nv2, eng2 = run(rows, 0)
+        small = {b: eng2.export_tree(i) for i, b in enumerate(sample)}
+        eng2.close()
+    else:           # PUCT tie-break noise is keyed by the tree id: one batch per id keeps it
+        small = {}
+        a2, v2, nv2 = np.zeros(len(rows), action.dtype), np.zeros(len(rows)), np.zeros(len(rows), nv.dtype)
+        for i, b in enumerate(sample[:12]):
+            ai, vi, ni, e = run(np.asarray([b]), tid0 + b)
+            a2[i], v2[i], nv2[i] = ai[0], vi[0], ni[0]
+            small[b] = e.export_tree(0)
+            e.close()
+        rows = rows[:12]
+        a2, v2, nv2 = a2[:12], v2[:12], nv2[:12]
+    np.testing.assert_array_equal(a2, action[rows])
+    np.testing.assert_array_equal(v2, root_value[rows])
+    np.testing.assert_array_equal(nv2, nv[rows])
+    for b, t in small.items():
+        assert_tree_equal(SimpleNamespace(**t), trees[b], hidden=True)
+
+
+def test_tictactoe_gumbel_16384_trees(monkeypatch):
+    B = 16384
+    rng = np.random.default_rng(2)
+    boards = rng.integers(0, 3, size=(B, 9)) - 1
+    obs = np.stack([(boards == -1), (boards == 1), np.ones_like(boards) * -1], axis=1).astype(np.float32).reshape(B, 27)
+    # The per-plane min-max scaling of a hidden state (9 cells) amplifies last-bit differences of a nearly flat plane, and
+    # these searches run 15 levels deep, so two float32 evaluators drift apart along a chain: no bound on hidden states,
+    # and root values (means over 100 leaf values) are compared at 5e-3 (median difference 3e-5).  What is exact is
+    # checked exactly: every leaf output within 1e-5 of the checker's on the SAME stored inputs, and the trees rebuilt
+    # bit for bit from the stored outputs.
+    _full_size('tictactoe', TICTACTOE, True, 9, 100, 2, 1, B, obs, lambda e: e.search_mfma(), True, 0.90, 1e-5, None,
+               monkeypatch, root_tol=5e-3)
+
+
+def test_cartpole_puct_8192_trees(monkeypatch):
+    B = 8192
+    obs = np.random.default_rng(3).uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32)
+    _full_size('cartpole', CARTPOLE, False, 2, 50, 1, 0.997, B, obs, lambda e: e.search_net(), False, 0.98, 1e-5, 1e-4,
+               monkeypatch)
+
+
+def test_atari_shaped_puct_1024_trees(monkeypatch):
+    B = 1024
+    obs = np.random.default_rng(4).standard_normal((B, 128)).astype(np.float32)
+    # 601-bin float32 expectations: two float32 evaluators agree to about 300 * 6e-8 * a few = 5e-5
+    _full_size('atari-shaped', ATARI_LIKE, False, 18, 200, 1, 0.997, B, obs, lambda e: e.search_mfma(), True, 0.88, 5e-5,
+               1e-4, monkeypatch)
