@@ -83,7 +83,7 @@ bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d
 
 static size_t gcache_dynamic_lds(const Dev &d, const MfmaNet &net, int tm)
 {
-    return ((size_t)net.stride + d.L.N + d.L.S) * tm * 4;
+    return ((size_t)net.stride + d.L.N + 2 * d.L.S + 1) * tm * 4;   // activations, decisions, paths, work list
 }
 
 bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm)
@@ -92,7 +92,7 @@ bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm)
     const Layout &L = d.L;
     const bool layout = L.prior_f32 && L.A == 9 && L.idx16 && L.rec == GL::rec && L.off_crew == GL::off_crew &&
                         L.off_prior == GL::off_prior && L.off_cvis == GL::off_cvis && L.off_cidx == GL::off_cidx;
-    const size_t stat = (size_t)tm * 16 * 8 + (size_t)tm * 9 * 8 + (size_t)tm * 24 + 64;  // the kernel's static arrays
+    const size_t stat = (size_t)tm * 16 * 8 + (size_t)tm * 9 * 8 + (size_t)tm * 20 + 64;  // the kernel's static arrays
     const bool sched = tm == 32 ? net.sched_ok8 : net.sched_ok4;
     return layout && sched && (tm == 32 || tm == 16) && gcache_dynamic_lds(d, net, tm) + stat <= 160 * 1024;
 }

@@ -95,16 +95,35 @@ __device__ __forceinline__ int rec_i16(const uint4 (&ch)[NCH])
 //   word = (children_index[node, action] + 1) << 8 | action      (an unexpanded edge gives 0 in the upper bits)
 // One lane evaluates one node from its record in global memory.  `gum`: the tree's Gumbel noise [A] (root only),
 // `cv_row`: the tree's sequential-halving schedule (root only).
+// The record as 16-byte chunks in registers (it is 64-byte aligned); every field sits at a compile-time position.
 template <int A>
-__device__ __forceinline__ int gumbel_decide(const Dev &d, const char *rec, bool is_root, unsigned long long legal,
-                                             const double *gum, const int32_t *cv_row)
+struct GumbelRec {
+    static constexpr int NCH = (GumbelLayout<A>::off_cidx + 2 * A + 15) / 16;
+    uint4 ch[NCH];
+};
+
+// Loads the chunks of `mask` (bit k = bytes 16 k .. 16 k + 15 of the record).
+template <int A>
+__device__ __forceinline__ void rec_load(GumbelRec<A> &r, const char *rec, unsigned mask)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(rec);
+    static_for<GumbelRec<A>::NCH>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if ((mask >> k) & 1u) r.ch[k] = src[k];
+    });
+}
+
+template <int A>
+__device__ __forceinline__ int gumbel_decide(const Dev &d, const GumbelRec<A> &rec, bool is_root, unsigned long long legal,
+                                             const double *gum, const int32_t *cv_row, long long *ld_cycles = nullptr)
 {
     using GL = GumbelLayout<A>;
-    // the record as 16-byte chunks (it is 64-byte aligned); every field below sits at a compile-time position
-    constexpr int NCH = (GL::off_cidx + 2 * A + 15) / 16;
-    uint4 ch[NCH];
-    const uint4 *src = reinterpret_cast<const uint4 *>(rec);
-    static_for<NCH>([&](auto K) { ch[decltype(K)::value] = src[decltype(K)::value]; });
+    constexpr int NCH = GumbelRec<A>::NCH;
+    const uint4 (&ch)[NCH] = rec.ch;
+#ifdef MZ_STAMPS
+    const long long ld_t0 = clock64();
+    if (ld_cycles) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); *ld_cycles += clock64() - ld_t0; }
+#endif
     const double inf = __builtin_huge_val();
     const double raw = rec_f64<24>(ch);
     double q[A];
@@ -152,6 +171,84 @@ __device__ __forceinline__ int gumbel_decide(const Dev &d, const char *rec, bool
     double den = hi - lo;
     den = den < 1e-8 ? 1e-8 : den;                                     // np.maximum: a NaN stays a NaN
     const double scale = (d.c_visit + (double)vmax) * d.c_scale;
+    // The chosen action needs an argmax, not the scores themselves.  The scores are first evaluated cheaply - one
+    // reciprocal per denominator instead of a correctly rounded division per action, float32 exponentials of
+    // max-shifted arguments - and the cheap argmax is taken when the best score leads the runner-up by more than the two
+    // evaluations can differ; every other case (near ties, exact ties, NaN or infinite scores, arguments near the range
+    // of exp) is evaluated with the reference's operations below.  Bounds, with t = (comp - lo) / den in [0, 1]:
+    //  * rden = 1/den after two Newton steps is within 3e-16 (relative) of the quotient's factor, so
+    //    |scale * t~ - scale * t| <= 1e-15 * scale, plus one rounding of each sum that follows (2.3e-16 relative);
+    //  * root: the same additions in the same order, so scores differ by at most 1e-15 * scale + a few ulp of the
+    //    operands; the lead demanded is 1e-10 * (scale + |best| + 1);
+    //  * interior: softmax(x)[a] is invariant under a common shift; with z = (x - xmax) * log2(e) split in float64 into
+    //    an integer n and a fraction |f| <= 1/2 (z itself is within 1e-13 of its exact value for z >= -200, and terms
+    //    below 2^-126 only matter as zeros), 2^f from v_exp_f32(float(f)) is within 2e-7 (relative: conversion 2e-8,
+    //    one ulp 1.2e-7) and the scaling by 2^n is exact; the float32 sum of A <= 16 terms (>= 1: the largest is
+    //    2^0) adds 1e-6, the reciprocal and product 2e-7, the float32 visit share 3e-7.  A cheap score is therefore
+    //    within 2e-6 of the exact one; the lead demanded is 1e-5.
+    int best = 0;
+    bool sure = false;
+#ifdef MZ_STAMPS
+    if (ld_cycles) { if (scale == 12345.678 && den == 3.25) ld_cycles[1]++; ld_cycles[3] += clock64() - ld_t0; }
+#endif
+#ifndef MZ_DECIDE_EXACT_ONLY
+    {
+        double rden = __builtin_amdgcn_rcp(den);
+        rden = __builtin_fma(__builtin_fma(-den, rden, 1.0), rden, rden);
+        rden = __builtin_fma(__builtin_fma(-den, rden, 1.0), rden, rden);
+        if (is_root) {
+            const int considered = cv_row[vsum < d.L.S ? vsum : d.L.S - 1];
+            float lmax = pf[0];
+#pragma unroll
+            for (int a = 1; a < A; a++) lmax = pf[a] > lmax ? pf[a] : lmax;
+            double b1 = -inf, b2 = -inf;
+            bool bad = false;
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                const double cq = scale * ((comp[a] - lo) * rden);
+                double sc = (gum[a] + (double)(pf[a] - lmax)) + cq;
+                bad = bad || sc != sc;
+                sc = sc < -1e9 ? -1e9 : sc;
+                sc = (cv[a] == considered && ((legal >> a) & 1ull)) ? sc : -inf;
+                if (sc > b1) { b2 = b1; b1 = sc; best = a; }
+                else if (sc > b2) b2 = sc;
+            }
+            sure = !bad && b1 > -1e300 && b1 < 1e300 && (b1 - b2) > 1e-10 * (scale + __builtin_fabs(b1) + 1.0);
+        } else {
+            double x[A];
+            double xmax = -inf;
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                x[a] = (double)pf[a] + scale * ((comp[a] - lo) * rden);
+                xmax = x[a] > xmax ? x[a] : xmax;
+            }
+            float ef[A], es = 0.0f;
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                // exp(x - xmax) = 2^n * 2^f with n an integer and |f| <= 1/2, both taken in float64: the float32
+                // conversion of f is then off by at most 3e-8 and v_exp_f32 by one ulp
+                const double z = (x[a] - xmax) * 1.4426950408889634;
+                const double n = __builtin_rint(z < -200.0 ? -200.0 : z);
+                ef[a] = __builtin_ldexpf(__builtin_amdgcn_exp2f((float)(z - n)), (int)n);
+                es += ef[a];
+            }
+            const float rs = __builtin_amdgcn_rcpf(es), rv = __builtin_amdgcn_rcpf((float)(1 + vsum));
+            float b1 = -__builtin_huge_valf(), b2 = -__builtin_huge_valf();
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                const float sc = ef[a] * rs - (float)cv[a] * rv;
+                if (sc > b1) { b2 = b1; b1 = sc; best = a; }
+                else if (sc > b2) b2 = sc;
+            }
+            // a NaN anywhere leaves the lead NaN (comparison false); exp(x) must stay finite and non-zero in float64
+            sure = (b1 - b2) > 1e-5f && __builtin_fabs(xmax) < 700.0;
+        }
+    }
+#endif
+#ifdef MZ_STAMPS
+    if (ld_cycles) { ld_cycles[1] += sure ? 0 : 1; ld_cycles[2] += __builtin_amdgcn_ballot_w64(!sure) ? 1 : 0; ld_cycles[4] += clock64() - ld_t0 + best * 0; }
+#endif
+    if (!sure) {
     double score[A];
     if (is_root) {   // gumbel_muzero_root_action_selection, mcts/action_selection.py:73-96 with gumbel_score :147-157
         const int considered = cv_row[vsum < d.L.S ? vsum : d.L.S - 1];
@@ -182,15 +279,19 @@ __device__ __forceinline__ int gumbel_decide(const Dev &d, const char *rec, bool
             score[a] = sc != sc ? inf : sc;
         }
     }
-    int best = 0;
+    best = 0;
     double bs = score[0];
 #pragma unroll
     for (int a = 1; a < A; a++) {
         if (score[a] > bs) { bs = score[a]; best = a; }                // first maximum
     }
+    }
     int child = 0;
 #pragma unroll
     for (int a = 0; a < A; a++) child = a == best ? ci[a] : child;
+#ifdef MZ_STAMPS
+    if (ld_cycles) ld_cycles[5] += clock64() - ld_t0 + child * 0;
+#endif
     return ((child + 1) << 8) | best;
 }
 
@@ -233,7 +334,10 @@ __device__ __forceinline__ void pool_locate(const PoolScan &p, int item, int *tr
     *j = item - (__shfl(p.incl, tr, 64) - __shfl(p.mine, tr, 64));
 }
 
-// Dynamic LDS: activations [TM][stride] floats | decisions int32 [TM][N] | paths int32 [TM][S].
+// An entry of the re-decision work list: tree of the tile (5 bits) | node (22 bits).
+__device__ __forceinline__ int item_word(int tree, int node) { return (int)((unsigned)tree << 27 | (unsigned)node); }
+
+// Dynamic LDS: activations [TM][stride] floats | decisions int32 [TM][N] | paths int32 [TM][S] | items int32 [TM][S + 1].
 template <int TM, int A>
 __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, int first_leaf, int n_sims)
 {
@@ -241,7 +345,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     __shared__ __align__(16) double s_bk[TM * 16];
     __shared__ __align__(16) double s_gum[TM * A];
     __shared__ unsigned long long s_legal[TM];
-    __shared__ int s_cvoff[TM], s_items[TM], s_depth[TM];
+    __shared__ int s_cvoff[TM], s_items[TM], s_total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tid / 16, a = tid % 16, t = blockIdx.x * TM + i;
     const int H = net.io[6], N = d.L.N, S = d.L.S;
@@ -249,6 +353,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     float *row = act + i * net.stride;
     int32_t *dec_all = reinterpret_cast<int32_t *>(act + TM * net.stride);
     int32_t *path_all = dec_all + TM * N;
+    int32_t *item_list = path_all + TM * S;   // the nodes to re-decide after a simulation (item_word below)
     double *bk = s_bk + i * 16;
     tile_zero<TM>(act, net.stride, tid);
     const int tt = live ? t : 0;  // groups past the end of the batch only keep the barriers company
@@ -275,8 +380,9 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             int tree, node;
             pool_locate<TM>(ps, base + tid, &tree, &node);
             if (base + tid < ps.total) {
-                const char *rec = tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec;
-                dec_all[tree * N + node] = gumbel_decide<A>(d, rec, node == 0, s_legal[tree], s_gum + tree * A,
+                GumbelRec<A> r;
+                rec_load<A>(r, tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec, ~0u);
+                dec_all[tree * N + node] = gumbel_decide<A>(d, r, node == 0, s_legal[tree], s_gum + tree * A,
                                                             d.cv_table + s_cvoff[tree]);
             }
         }
@@ -284,7 +390,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     __syncthreads();
 #ifdef MZ_STAMPS
     long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_t = clock64();
-    long long sx[6] = {0, 0, 0, 0, 0, 0}, sx_t = 0;   // finer: walk | epilogue | expansion+backup | fence | (barrier) | decision loads
+    long long sx[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sx_t = 0;   // finer: walk | epilogue | expansion+backup | fence | (barrier) | decision loads
 #define MZ_XSTAMP(k) { long long n_ = clock64(); sx[k] += n_ - sx_t; sx_t = n_; }
 #define MZ_XSTART() { sx_t = clock64(); }
 #else
@@ -311,6 +417,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             parent = node;
             ntp = d.players == 1 ? 0 : (depth & 1);  // starts at player 0, flips once per level (mcts/mcts.py:105,112)
             visited += depth + 1;
+            if (a == 0) s_items[i] = depth < S ? depth : S;   // path nodes whose records this simulation changes
             MZ_XSTAMP(0)
             tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
             bp = backup_prefetch<16>(d, m, a, depth);   // the path's records travel while the network runs
@@ -320,6 +427,17 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
         tile_wload(nb, ts, 0, lane, wf);
         lds_barrier();
         MZ_MSTAMP(st_b)
+        // The work list of this simulation's re-decision phase, made while nothing waits for it: every group puts its
+        // path's nodes behind those of the groups before it (exclusive prefix of the path lengths by a 16-lane sum), so
+        // the phase itself starts with one LDS read per thread instead of a search through prefix sums.
+        {
+            int before = 0;
+            for (int k = a; k < TM; k += 16) before += k < i ? s_items[k] : 0;
+            before = gsumi<16>(before);
+            const int np = live ? (depth < S ? depth : S) : 0;
+            for (int j = a; j < np; j += 16) item_list[before + j] = item_word(i, m.path[j] >> 6);
+            if (tid == TM * 16 - 1) s_total = before + np;
+        }
         tile_run_levels<TM>(net, nb, act, ts, lane, wf);
         MZ_MSTAMP(st_c)
         MZ_XSTART()
@@ -332,7 +450,25 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             MZ_XSTAMP(1)
 #endif
             expand_backup<16, true, true>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, bk, &bp);
-            if (a == 0) { s_items[i] = depth + 1; s_depth[i] = depth; }
+            // The new leaf's decision needs no record: nothing below it is visited, every completed value is the
+            // leaf's raw value, the value term of the interior rule is scale * ((raw - raw) / 1e-8) = 0 and the scores
+            // are exp(logit) / sum - 0 (mcts/action_selection.py:99-118, mcts/qtransforms.py:25-48): the first largest
+            // logit.  exp and the division by a common sum keep a lead of 1e-4 between logits strict (a factor
+            // 1 + 1e-4 against errors of a few ulp), so with such a lead, a finite raw value and exp(best) neither 0
+            // nor infinite the decision is written here; otherwise the leaf joins the work list.
+            {
+                const float ninf = -__builtin_huge_valf();
+                const float l1 = on ? lg : ninf;
+                const int nans = gsumi<16>((on && lg != lg) ? 1 : 0);
+                const float m1 = gmaxf<16>(l1);
+                const int best = gargmax<16>((double)l1, on ? a : 64);
+                const float m2 = gmaxf<16>((on && a != best) ? lg : ninf);
+                const bool sure = nans == 0 && (m1 - m2) > 1e-4f && m1 < 700.0f && m1 > -700.0f && (value - value) == 0.0;
+                if (a == 0) {
+                    if (sure) dec[leaf] = best;   // children_index is -1 on a fresh record: (-1 + 1) << 8 | action
+                    else item_list[atomicAdd(&s_total, 1)] = item_word(i, leaf);
+                }
+            }
 #ifdef MZ_STAMPS
             MZ_XSTAMP(2)
 #endif
@@ -346,17 +482,27 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
         MZ_XSTAMP(4)
 #endif
         MZ_MSTAMP(st_d)
-        // the nodes whose records changed: levels 0..depth-1 of each tree's path, and its new leaf
+        // the nodes whose records changed: the work list (path nodes, and leaves without a certified decision), one
+        // lane per node
         {
-            const PoolScan ps = pool_scan<TM>(s_items, lane);
-            for (int base = 0; base < ps.total; base += TM * 16) {
-                int tree, j;
-                pool_locate<TM>(ps, base + tid, &tree, &j);
-                if (base + tid < ps.total) {
-                    const int node = j < s_depth[tree] ? (path_all[tree * S + j] >> 6) : leaf;
-                    const char *rec = tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec;
-                    dec_all[tree * N + node] = gumbel_decide<A>(d, rec, node == 0, s_legal[tree], s_gum + tree * A,
+#ifdef MZ_STAMPS
+            const long long ph_t0 = clock64();
+#endif
+            const int total = s_total;
+            for (int base = 0; base < total; base += TM * 16) {
+                if (base + tid < total) {
+                    const int w = item_list[base + tid];
+                    const int tree = (int)((unsigned)w >> 27), node = w & 0x3fffff;
+                    GumbelRec<A> grec;
+                    rec_load<A>(grec, tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec, ~0u);
+#ifdef MZ_STAMPS
+                    sx[11] += clock64() - ph_t0 + node * 0;
+                    dec_all[tree * N + node] = gumbel_decide<A>(d, grec, node == 0, s_legal[tree], s_gum + tree * A,
+                                                                d.cv_table + s_cvoff[tree], &sx[5]);
+#else
+                    dec_all[tree * N + node] = gumbel_decide<A>(d, grec, node == 0, s_legal[tree], s_gum + tree * A,
                                                                 d.cv_table + s_cvoff[tree]);
+#endif
                 }
             }
         }
@@ -367,7 +513,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     if (live && a == 0) {  // diagnostic build only: [walk+stage, barrier wait, network, epilogue+backup, decisions] cycles
         long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
         o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = st_d; o[4] = st_e;
-        for (int k = 0; k < 5; k++) o[5 + k] = sx[k];
+        for (int k = 0; k < 12; k++) o[5 + k] = sx[k];
     }
 #endif
     if (live && a == 0) d.visit_total[t] += visited;
