@@ -94,7 +94,10 @@ bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm)
                         L.off_prior == GL::off_prior && L.off_cvis == GL::off_cvis && L.off_cidx == GL::off_cidx;
     const size_t stat = (size_t)tm * 16 * 8 + (size_t)tm * 9 * 8 + (size_t)tm * 20 + 64;  // the kernel's static arrays
     const bool sched = tm == 32 ? net.sched_ok8 : net.sched_ok4;
-    return layout && sched && (tm == 32 || tm == 16) && gcache_dynamic_lds(d, net, tm) + stat <= 160 * 1024;
+    // the re-decision phase stages records in the (then idle) activations, one area per wave, and addresses a tile's
+    // records by 32-bit offsets
+    const bool stage = (size_t)tm * net.stride * 4 >= (size_t)(tm / 4) * MZ_GC_STAGE && (long long)tm * L.tree_stride < 0x7fffffffLL;
+    return layout && sched && stage && (tm == 32 || tm == 16) && gcache_dynamic_lds(d, net, tm) + stat <= 160 * 1024;
 }
 
 hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims)

@@ -334,6 +334,43 @@ __device__ __forceinline__ void pool_locate(const PoolScan &p, int item, int *tr
     *j = item - (__shfl(p.incl, tr, 64) - __shfl(p.mine, tr, 64));
 }
 
+// The records of a wave's 64 work-list nodes, fetched so that the memory pipeline sees whole cache lines: with one lane
+// per node every 16-byte load of a wave touches 64 different lines (64 tag look-ups per instruction: the re-decision
+// phase spent half its time there).  Here 8 lanes read the 128 bytes of one line, 8 records per instruction, the wave
+// parks the lines in LDS and every lane reads its own record's chunks back; the record's two lines take turns in the
+// same staging area.  `stage`: MZ_GC_STAGE bytes of LDS owned by the wave (the tile's activations, idle in this phase:
+// the caller zeroes them again afterwards), `off`: byte offset of the lane's record from `base`, negative = no record.
+#define MZ_GC_STAGE (64 * 144 + 256)   // 64 lines of 128 bytes, 16 bytes apart (conflict-free 16-byte reads) + 64 offsets
+template <int A>
+__device__ __forceinline__ void rec_fetch_staged(GumbelRec<A> &r, const char *base, int off, char *stage, int lane)
+{
+    constexpr int NCH = GumbelRec<A>::NCH;
+    static_assert(NCH > 8 && NCH <= 16, "a record of two 128-byte lines");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: arrays of it become registers
+    int32_t *offs = reinterpret_cast<int32_t *>(stage + 64 * 144);
+    u32x4 *st = reinterpret_cast<u32x4 *>(stage);
+    offs[lane] = off;   // lanes without a node pass the offset of any record: loaded, never used
+    lds_fence();
+    const int sub = lane & 7, grp = lane >> 3;
+    int so[8];
+    u32x4 ln[8];
+    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; so[k] = offs[8 * k + grp] + 16 * sub; });
+    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; ln[k] = *reinterpret_cast<const u32x4 *>(base + so[k]); });
+    __builtin_amdgcn_sched_barrier(0);   // all eight loads in flight before the first store waits for its data
+    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; st[(8 * k + grp) * 9 + sub] = ln[k]; });
+    __builtin_amdgcn_sched_barrier(0);
+    // the second lines are on their way during the reads below
+    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; ln[k] = *reinterpret_cast<const u32x4 *>(base + so[k] + 128); });
+    __builtin_amdgcn_sched_barrier(0);
+    lds_fence();
+    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; r.ch[k] = __builtin_bit_cast(uint4, st[lane * 9 + k]); });
+    lds_fence();
+    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; st[(8 * k + grp) * 9 + sub] = ln[k]; });
+    lds_fence();
+    static_for<NCH - 8>([&](auto K) { constexpr int k = decltype(K)::value; r.ch[8 + k] = __builtin_bit_cast(uint4, st[lane * 9 + k]); });
+    lds_fence();
+}
+
 // An entry of the re-decision work list: tree of the tile (5 bits) | node (22 bits).
 __device__ __forceinline__ int item_word(int tree, int node) { return (int)((unsigned)tree << 27 | (unsigned)node); }
 
@@ -489,12 +526,15 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             const long long ph_t0 = clock64();
 #endif
             const int total = s_total;
+            char *stage = reinterpret_cast<char *>(act) + wave * MZ_GC_STAGE;
             for (int base = 0; base < total; base += TM * 16) {
-                if (base + tid < total) {
-                    const int w = item_list[base + tid];
-                    const int tree = (int)((unsigned)w >> 27), node = w & 0x3fffff;
-                    GumbelRec<A> grec;
-                    rec_load<A>(grec, tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec, ~0u);
+                const bool has = base + tid < total;
+                const int w = has ? item_list[base + tid] : 0;
+                const int tree = (int)((unsigned)w >> 27), node = w & 0x3fffff;
+                GumbelRec<A> grec;
+                if (base + (wave << 6) >= total) continue;   // wave-uniform: none of the wave's lanes has a node
+                rec_fetch_staged<A>(grec, tile_nodes, has ? tree * (int)d.L.tree_stride + node * GumbelLayout<A>::rec : 0, stage, lane);
+                if (has) {
 #ifdef MZ_STAMPS
                     sx[11] += clock64() - ph_t0 + node * 0;
                     dec_all[tree * N + node] = gumbel_decide<A>(d, grec, node == 0, s_legal[tree], s_gum + tree * A,
@@ -504,6 +544,10 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
                                                                 d.cv_table + s_cvoff[tree]);
 #endif
                 }
+            }
+            if ((wave << 6) < total) {   // the staging area goes back to the network as zeros
+                uint4 *st = reinterpret_cast<uint4 *>(stage);
+                for (int k = lane; k < MZ_GC_STAGE / 16; k += 64) st[k] = uint4{0, 0, 0, 0};
             }
         }
         __syncthreads();
