@@ -342,8 +342,12 @@ __device__ __forceinline__ void pool_locate(const PoolScan &p, int item, int *tr
 // the caller zeroes them again afterwards), `off`: byte offset of the lane's record from `base`, negative = no record.
 #define MZ_GC_STAGE (64 * 144 + 256)   // 64 lines of 128 bytes, 16 bytes apart (conflict-free 16-byte reads) + 64 offsets
 template <int A>
-__device__ __forceinline__ void rec_fetch_staged(GumbelRec<A> &r, const char *base, int off, char *stage, int lane)
+__device__ __forceinline__ void rec_fetch_staged(GumbelRec<A> &r, const char *base, int off, char *stage, int lane,
+                                                 long long *stamps = nullptr)
 {
+#ifdef MZ_STAMPS
+    const long long ft0 = clock64();
+#endif
     constexpr int NCH = GumbelRec<A>::NCH;
     static_assert(NCH > 8 && NCH <= 16, "a record of two 128-byte lines");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: arrays of it become registers
@@ -357,6 +361,9 @@ __device__ __forceinline__ void rec_fetch_staged(GumbelRec<A> &r, const char *ba
     static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; so[k] = offs[8 * k + grp] + 16 * sub; });
     static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; ln[k] = *reinterpret_cast<const u32x4 *>(base + so[k]); });
     __builtin_amdgcn_sched_barrier(0);   // all eight loads in flight before the first store waits for its data
+#ifdef MZ_STAMPS
+    if (stamps) { stamps[0] += clock64() - ft0; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[1] += clock64() - ft0; }
+#endif
     static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; st[(8 * k + grp) * 9 + sub] = ln[k]; });
     __builtin_amdgcn_sched_barrier(0);
     // the second lines are on their way during the reads below
@@ -369,6 +376,9 @@ __device__ __forceinline__ void rec_fetch_staged(GumbelRec<A> &r, const char *ba
     lds_fence();
     static_for<NCH - 8>([&](auto K) { constexpr int k = decltype(K)::value; r.ch[8 + k] = __builtin_bit_cast(uint4, st[lane * 9 + k]); });
     lds_fence();
+#ifdef MZ_STAMPS
+    if (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamps[2] += clock64() - ft0 + (long long)(r.ch[9].x & 0); }
+#endif
 }
 
 // An entry of the re-decision work list: tree of the tile (5 bits) | node (22 bits).
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     __syncthreads();
 #ifdef MZ_STAMPS
     long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_t = clock64();
-    long long sx[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sx_t = 0;   // finer: walk | epilogue | expansion+backup | fence | (barrier) | decision loads
+    long long sx[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sx_t = 0;   // finer: walk | epilogue | expansion+backup | fence | (barrier) | decision loads
 #define MZ_XSTAMP(k) { long long n_ = clock64(); sx[k] += n_ - sx_t; sx_t = n_; }
 #define MZ_XSTART() { sx_t = clock64(); }
 #else
@@ -533,7 +543,11 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
                 const int tree = (int)((unsigned)w >> 27), node = w & 0x3fffff;
                 GumbelRec<A> grec;
                 if (base + (wave << 6) >= total) continue;   // wave-uniform: none of the wave's lanes has a node
+                #ifdef MZ_STAMPS
+                rec_fetch_staged<A>(grec, tile_nodes, has ? tree * (int)d.L.tree_stride + node * GumbelLayout<A>::rec : 0, stage, lane, &sx[12]);
+#else
                 rec_fetch_staged<A>(grec, tile_nodes, has ? tree * (int)d.L.tree_stride + node * GumbelLayout<A>::rec : 0, stage, lane);
+#endif
                 if (has) {
 #ifdef MZ_STAMPS
                     sx[11] += clock64() - ph_t0 + node * 0;
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     if (live && a == 0) {  // diagnostic build only: [walk+stage, barrier wait, network, epilogue+backup, decisions] cycles
         long long *o = reinterpret_cast<long long *>(d.path + (long long)t * d.L.S);
         o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = st_d; o[4] = st_e;
-        for (int k = 0; k < 12; k++) o[5 + k] = sx[k];
+        for (int k = 0; k < 16; k++) o[5 + k] = sx[k];
     }
 #endif
     if (live && a == 0) d.visit_total[t] += visited;

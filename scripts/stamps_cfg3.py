@@ -27,7 +27,7 @@ buf = np.zeros((B, S), np.int32)
 lib().mz_debug_read_path(C.c_void_p(eng._ctx), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes))
 cached = os.environ.get('MZ_SEARCH_CACHED', '1') != '0'
 n = 5 if cached else 4
-fine = buf.view(np.int64).reshape(B, S // 2)[:, 5:17].astype(np.float64) if cached else None
+fine = buf.view(np.int64).reshape(B, S // 2)[:, 5:21].astype(np.float64) if cached else None
 st = buf.view(np.int64).reshape(B, S // 2)[:, :n].astype(np.float64)
 names = ['walk/descend+stage', 'barrier wait', 'network', 'epilogue+backup'] + (['decisions'] if cached else [])
 print('shader-clock cycles per simulation, mean over trees: ' +
@@ -36,7 +36,7 @@ if fine is not None:
     print('   of which: walk %.0f (the rest of the first phase stages the inputs)  epilogue %.0f  expansion + backup %.0f  '
           'wait for the stores %.0f  barrier %.0f  record loads of the re-decision (lane 0 of each tree) %.0f' % tuple(fine[:, :6].mean(0) / S))
     print('   decisions evaluated with the reference operations (no certified lead): %.4f per lane and simulation; waves that ran that path: %.3f per simulation' % tuple(fine[:, 6:8].mean(0) / S))
-    print('   inside one decision (cycles from its start, cumulative): loads %.0f  completed values + range %.0f  certified argmax %.0f  end %.0f' % tuple(fine[:, [5, 8, 9, 10]].mean(0) / S) + '  (the decision starts %.0f cycles into its phase)' % (fine[:, 11].mean() / S))
+    print('   inside one decision (cycles from its start, cumulative): loads %.0f  completed values + range %.0f  certified argmax %.0f  end %.0f' % tuple(fine[:, [5, 8, 9, 10]].mean(0) / S) + '  (the decision starts %.0f cycles into its phase; the record fetch has issued its first eight loads after %.0f and holds their data after %.0f, ends after %.0f: between the start of the phase and the fetch lies the wait for the stores of the backup)' % tuple(fine[:, [11, 12, 13, 14]].mean(0) / S))
 lv = np.zeros(8 * 1024, np.int64)
 f = lib().mz_debug_read_net_stamps
 f.argtypes = [C.c_void_p, C.c_int]
