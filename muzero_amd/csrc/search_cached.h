@@ -477,13 +477,17 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
         // The work list of this simulation's re-decision phase, made while nothing waits for it: every group puts its
         // path's nodes behind those of the groups before it (exclusive prefix of the path lengths by a 16-lane sum), so
         // the phase itself starts with one LDS read per thread instead of a search through prefix sums.
+        // The roots come first (the live trees are the tile's first ones, and every path starts at its root): the root
+        // rule and the interior rule are different code, and a wave whose lanes are all of one kind runs only that one.
         {
+            const int n_live = d.B - (int)blockIdx.x * TM < TM ? d.B - (int)blockIdx.x * TM : TM;
             int before = 0;
-            for (int k = a; k < TM; k += 16) before += k < i ? s_items[k] : 0;
-            before = gsumi<16>(before);
+            for (int k = a; k < TM; k += 16) before += (k < i && s_items[k] > 0) ? s_items[k] - 1 : 0;
+            before = n_live + gsumi<16>(before);
             const int np = live ? (depth < S ? depth : S) : 0;
-            for (int j = a; j < np; j += 16) item_list[before + j] = item_word(i, m.path[j] >> 6);
-            if (tid == TM * 16 - 1) s_total = before + np;
+            if (a == 0 && np > 0) item_list[i] = item_word(i, 0);
+            for (int j = 1 + a; j < np; j += 16) item_list[before + j - 1] = item_word(i, m.path[j] >> 6);
+            if (tid == TM * 16 - 1) s_total = before + (np > 0 ? np - 1 : 0);
         }
         tile_run_levels<TM>(net, nb, act, ts, lane, wf);
         MZ_MSTAMP(st_c)
