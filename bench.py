@@ -404,8 +404,9 @@ LIMITER = {
             'latency of ~1000 dependent instructions per simulation',
     'mfma': 'per simulation a 32-tree block walks a cached decision table in LDS, runs the float32 matrix-core network of its '
             'tile (block-sparse weights streamed from L2), then the float64 epilogue, backup and re-decision of the path '
-            'nodes; the shader-sequencer counters show waves parked on waits 46% and stalled on issue 26% of their cycles: '
-            'neither HBM (measured traffic 1.6 TB/s) nor the matrix pipes (17% busy) saturate',
+            'nodes (cheap scores with a certified argmax, the reference operations only without a certified lead); the '
+            'shader-sequencer counters show waves parked on waits 47% and stalled on issue 25% of their cycles: neither '
+            'HBM (measured traffic 2.0 TB/s) nor the matrix pipes (20% busy) saturate',
     'mfma_levels': 'a chain of three launches per simulation over only 1024 trees: every launch is bound by its own start-up, '
                    'memory round trips and drain (matrix instructions are 3.3 of a level launch\'s 13.7 us), and the chain '
                    'is serial by construction (the next selection needs this backup)',

@@ -93,3 +93,51 @@ def test_cached_decisions_on_degenerate_priors(monkeypatch):
     for tw, tg in zip(want['trees'], got['trees']):
         for k in tw:
             np.testing.assert_array_equal(tw[k], tg[k], err_msg=k)
+
+
+@pytest.mark.parametrize('mode', ['tied', 'near_tied', 'deep'])
+def test_decisions_without_a_certified_lead(mode, monkeypatch):
+    """The cached-decision kernel takes a cheap argmax only when its lead is certified.  Policy heads that leave it no
+    lead: identical logits for every action (every leaf joins the work list, every interior score is an exact tie:
+    the reference's first-maximum rule decides), logits a few float32 ulps apart (the lead exists but is far below
+    what the cheap evaluation resolves), and a head that prefers one action so strongly that every path is a chain as
+    deep as the search is long (work lists of several rounds per simulation)."""
+    from muzero_amd.packing import pack_network_mfma
+    z, net0 = load_net('resnet_tictactoe')
+    sd = {k: v.clone() for k, v in net0.state_dict().items()}
+    wkey = [k for k in sd if 'policy' in k and k.endswith('weight')][-1]
+    bkey = [k for k in sd if 'policy' in k and k.endswith('bias')][-1]
+    if mode == 'tied':
+        sd[wkey].zero_(); sd[bkey].fill_(0.25)
+    elif mode == 'near_tied':
+        sd[wkey].zero_()
+        sd[bkey].copy_(torch.tensor(np.float32(0.25) + np.arange(9, dtype=np.float32) * np.float32(3e-8)))
+    else:
+        sd[wkey].zero_(); sd[bkey].zero_(); sd[bkey][7] = 85.0      # exp(85) is still a finite float32
+        for head in ('value', 'reward'):                             # and no value differences to argue with it
+            sd[[k for k in sd if head in k and k.endswith('weight')][-1]].zero_()
+    net = MuZeroNetwork(net_config('resnet_tictactoe'), sd).to('cuda')
+    pm_io = pack_network_mfma(net)
+    rng = np.random.default_rng(5)
+    B, S = 40, 90
+    cfg = make_config(True, 9, S, 2, 1)
+    obs = z['obs'][rng.integers(0, len(z['obs']), size=B)].astype(np.float32)
+    with torch.no_grad():
+        logits, hidden, value = net.initial_flat(torch.as_tensor(obs.reshape(B, -1), device='cuda'))
+    legal = np.ones((B, 9))
+    legal[::5, 2:5] = 0
+    if mode == 'deep':                           # roots with one legal move: the whole search is one chain
+        legal[1::2] = 0
+        legal[1::2, 7] = 1
+    tp = rng.integers(0, 2, size=B).astype(np.int32)
+    g = rng.gumbel(size=(B, 9))
+    want = _run(monkeypatch, False, 32, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
+    if mode == 'deep':
+        assert want['nv'].max() > S * S // 3     # leaf depth grows with every simulation
+    for tm in (32, 16):
+        got = _run(monkeypatch, True, tm, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
+        for k in ('action', 'value', 'probs', 'q', 'nv'):
+            np.testing.assert_array_equal(want[k], got[k], err_msg=f'{k} tm={tm}')
+        for tw, tg in zip(want['trees'], got['trees']):
+            for k in tw:
+                np.testing.assert_array_equal(tw[k], tg[k], err_msg=f'{k} tm={tm}')
