@@ -450,7 +450,11 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
         int ctm = 32;
         if (const char *e = getenv("MZ_SEARCH_TM")) ctm = atoi(e) == 16 ? 16 : 32;
         bool cached = c->cfg.gumbel && search_gcache_supported(c->d, c->mnet, ctm);
-        if (const char *e = getenv("MZ_SEARCH_CACHED")) cached = cached && atoi(e) != 0;
+        if (const char *e = getenv("MZ_SEARCH_CACHED")) {   // 0: never, 2: demanded (tests that must not pass vacuously)
+            if (atoi(e) == 2 && !cached)
+                return fail(MZ_ERR_ARG, "mz_search_run: the cached-decision kernel does not serve this configuration");
+            cached = cached && atoi(e) != 0;
+        }
         hipError_t attr_err;
         if (cached) {
             attr_err = launch_search_gcache(ctm, (hipStream_t)stream, c->d, c->mnet, c->n_expanded + 1, n_sims);

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _run(monkeypatch, cached, tm, cfg, net, pm_io, logits, hidden, value, legal, tp, g, stepped, B):
     from muzero_amd.engine import SearchEngine
-    monkeypatch.setenv('MZ_SEARCH_CACHED', '1' if cached else '0')
+    monkeypatch.setenv('MZ_SEARCH_CACHED', '2' if cached else '0')   # 2: an error if the kernel does not serve the case
     monkeypatch.setenv('MZ_SEARCH_TM', str(tm))
     eng = SearchEngine(cfg, net.H, B, seed=2)
     eng.set_network_mfma(*pm_io)
