@@ -191,7 +191,6 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         den0 = den0 < 1e-8 ? 1e-8 : den0;
         const double lo1 = lo0, den1 = den0;
         const double cq0 = cv0 > 0 ? q0 : lo0, cq1 = cv1 > 0 ? q1 : lo1;
-        const double nq0 = (cq0 - lo0) / den0, nq1 = (cq1 - lo1) / den1;
         double cc;
         if (ct) {
             cc = ct[nv];  // LDS
@@ -202,11 +201,28 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_search_reg(Dev d, NetDev net, int 
         const double sq0 = sqt ? sqt[nv * (S + 1) + cv0] : sqrt((double)nv / (double)(1 + cv0));
         const double sq1 = sqt ? sqt[nv * (S + 1) + cv1] : sqrt((double)nv / (double)(1 + cv1));
         const double uu0 = cc * pr0 + sq0, uu1 = cc * pr1 + sq1;
-        double sc0 = (uu0 + nq0) + 1e-7 * u0, sc1 = (uu1 + nq1) + 1e-7 * u1;
-        sc0 = sc0 != sc0 ? inf : sc0; sc1 = sc1 != sc1 ? inf : sc1;  // np.argmax: a NaN is the maximum
-        if (!legal0) sc0 = -inf;
-        if (!legal1) sc1 = -inf;
-        const int best = sc1 > sc0 ? 1 : 0;  // first maximum
+        // The rule needs the larger of two scores, not the scores.  Both transformed values divide by the same range:
+        // with its reciprocal (two Newton steps: within 3e-16 of the quotient's factor) each is within 4e-16 of the
+        // correctly rounded division, the sums that follow add a few ulp of their operands, so the cheap scores are
+        // within 1e-14 * (1 + |uu0| + |uu1|) of the reference's, and their order is the reference's whenever they
+        // differ by more than that (the tie-break term alone, 1e-7 * |u0 - u1|, is usually 10^5 times larger).  Only
+        // the remaining cases - and NaN or doubly illegal scores, whose difference is NaN - divide.
+        double rden = __builtin_amdgcn_rcp(den0);
+        rden = __builtin_fma(__builtin_fma(-den0, rden, 1.0), rden, rden);
+        rden = __builtin_fma(__builtin_fma(-den0, rden, 1.0), rden, rden);
+        double f0 = (uu0 + (cq0 - lo0) * rden) + 1e-7 * u0, f1 = (uu1 + (cq1 - lo1) * rden) + 1e-7 * u1;
+        if (!legal0) f0 = -inf;
+        if (!legal1) f1 = -inf;
+        const double lead = f1 - f0;
+        int best = lead > 0.0 ? 1 : 0;
+        if (!(__builtin_fabs(lead) > 1e-14 * (1.0 + __builtin_fabs(uu0) + __builtin_fabs(uu1)))) {
+            const double nq0 = (cq0 - lo0) / den0, nq1 = (cq1 - lo1) / den1;
+            double sc0 = (uu0 + nq0) + 1e-7 * u0, sc1 = (uu1 + nq1) + 1e-7 * u1;
+            sc0 = sc0 != sc0 ? inf : sc0; sc1 = sc1 != sc1 ? inf : sc1;  // np.argmax: a NaN is the maximum
+            if (!legal0) sc0 = -inf;
+            if (!legal1) sc1 = -inf;
+            best = sc1 > sc0 ? 1 : 0;  // first maximum
+        }
         const int chosen_child = best ? ci1 : ci0;
         const int pack = ((chosen_child + 1) << 8) | best;
         // ---- descent: follow the decisions from the root
