@@ -12,9 +12,12 @@
 //   3. expands and backs up (tree_ops.h expand_backup), and
 //   4. re-decides exactly the nodes whose records changed - the path and the new leaf - all at once:
 //      one LANE per node, looping over the actions in registers (no cross-lane reductions, no idle action lanes),
-//      the (tree, level) pairs of the block's whole tile dealt evenly over its threads.
-// Every expression and operand order is the lane-group kernels' (tree_ops.h select_at and what it calls), with the
-// group reductions replaced by their serial equivalents, so trees come out bit for bit the same.
+//      the path nodes of the block's whole tile on one work list (made before the network runs) dealt evenly over
+//      its threads, the new leaf decided from its logits where they have a clear leader.
+// A decision is an argmax: it is taken from cheap scores when their lead is certified to exceed what the cheap and the
+// reference evaluation can differ by (gumbel_decide).  Everything else - and every other case - uses the expressions
+// and operand order of the lane-group kernels (tree_ops.h select_at and what it calls), with the group reductions
+// replaced by their serial equivalents, so trees come out bit for bit the same.
 // PUCT does not qualify: its score contains a fresh tie-break draw per selection call (mcts/action_selection.py:46).
 #pragma once
 #include <utility>
@@ -299,7 +302,7 @@ template <int TM> struct Log2 { static constexpr int value = 1 + Log2<TM / 2>::v
 template <> struct Log2<1> { static constexpr int value = 0; };
 
 // Deals the items of the tile's trees (tree l has s_items[l] of them, numbered 0..s_items[l]-1) evenly over the block's
-// threads.  Every wave derives the same prefix sums from s_items in LDS and keeps them in its lanes 0..TM-1.
+// threads: used once per launch, for the nodes that exist when the kernel starts (the simulations keep a work list).  Every wave derives the same prefix sums from s_items in LDS and keeps them in its lanes 0..TM-1.
 struct PoolScan { int mine, incl, total; };
 
 template <int TM>
