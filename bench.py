@@ -170,6 +170,7 @@ def main():
         B = int(os.environ['MZ_BENCH_TREES'])
         desc += f' [experiment: {B} trees]'
     leaf_macs = None
+    root_on_device = False
     cfg = search_config(gumbel, A, S, players, gamma)
     rng = np.random.default_rng(1 + rank)
     tree_id0 = rank * B
@@ -220,6 +221,10 @@ def main():
         pm_io = pack_network_mfma(net)
         leaf_macs = (pm_io[0].macs, pm_io[0].padded_macs)
         eng.set_network_mfma(*pm_io)
+        if leaf in ('mfma', 'mfma_step'):
+            from muzero_amd.packing import pack_root_network_mfma
+            eng.set_root_network_mfma(*pack_root_network_mfma(net))
+            root_on_device = True
         obs = torch.as_tensor(rng.standard_normal((B, 128)).astype(np.float32), device=dev)
     elif leaf in ('step', 'mfma', 'mfma_step'):
         from muzero_amd.packing import pack_network_mfma
@@ -229,6 +234,10 @@ def main():
         pm_io = pack_network_mfma(net)
         leaf_macs = (pm_io[0].macs, pm_io[0].padded_macs)
         eng.set_network_mfma(*pm_io)
+        if leaf in ('mfma', 'mfma_step'):   # the roots, too, are evaluated by the engine (mz_initial_inference_mfma)
+            from muzero_amd.packing import pack_root_network_mfma
+            eng.set_root_network_mfma(*pack_root_network_mfma(net))
+            root_on_device = True
         obs = torch.as_tensor(tictactoe_roots(rng, B).reshape(B, 27), device=dev)
     else:
         H = 144 if A == 9 else 256
@@ -288,7 +297,7 @@ def main():
         if leaf == 'mlp':
             eng.begin_net(obs, legal, to_play, dirichlet, 0.25, gnoise, tree_id0=tree_id0)
         elif leaf in ('step', 'mfma', 'mfma_step', 'step5'):
-            lg0, hid0, val0 = net.initial_flat(obs)
+            lg0, hid0, val0 = eng.initial_inference_mfma(obs) if root_on_device else net.initial_flat(obs)
             prior = eng.root_prepare(lg0, legal, dirichlet, 0.25)
             eng.reset(prior, val0, hid0, to_play, legal, gnoise, tree_id0=tree_id0)
         else:

@@ -158,6 +158,26 @@ int mz_set_network_mfma(mz_ctx *ctx, const int32_t *steps_h, int32_t n_steps, in
                         const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
                         const int32_t *io_h);
 
+/* The two programs of network.initial_inference (network.py:86-103) in the same matrix-core layout, for
+ * mz_initial_inference_mfma: part 0 = the representation network (observation -> raw hidden state; io_h[0] = where the
+ * observation of io_h[11] floats goes in the activation row, io_h[2] = where the raw hidden state comes out), part 1 =
+ * the prediction network on the scaled hidden state (io_h[0] = where the hidden state goes, io_h[8] = 0: no action
+ * beside it, io_h[4] / io_h[5] = policy logits / value logits).  Other arguments and io_h entries as in
+ * mz_set_network_mfma. */
+int mz_set_root_network_mfma(mz_ctx *ctx, int32_t part, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
+                             const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
+                             const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
+                             const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
+                             const int32_t *io_h);
+
+/* Replaces network.initial_inference (network.py:86-103, called by MCTS.search at mcts/mcts.py:176-180) for B
+ * observations: representation network, per-group min-max scaling of the hidden state (utils/network_utils.py:132-158),
+ * prediction network, support_to_scalar of the value (utils/network_utils.py:75-96), level by level on the matrix
+ * cores.  obs float[B][obs_size], out_logits float[B][n_actions], out_hidden float[B][hidden_size] (the reference's
+ * element order), out_value double[B]; all device pointers.  The outputs are what mz_root_prepare / mz_tree_reset take. */
+int mz_initial_inference_mfma(mz_ctx *ctx, int32_t B, const float *obs, float *out_logits, float *out_hidden,
+                              double *out_value, void *stream);
+
 /* Replaces network.recurrent_inference (mcts/mcts.py:240-243) + MCTS.expand + MCTS.backward
  * (mcts/mcts.py:116-164) for the pending selection of every tree: leaves are evaluated on the matrix
  * cores by the network given to mz_set_network_mfma, then expanded and backed up.  With select_next != 0

@@ -60,7 +60,15 @@ struct mz_ctx {
     bool mnet_tile_fits;               // a 16-tree activation tile fits in LDS (tile-resident kernels usable)
     float *leaf_logits; // [max_batch][A] outputs of the batched leaf evaluation
     double *leaf_value, *leaf_reward;
+    // representation and prediction programs of the initial inference in matrix-core layout (mz_set_root_network_mfma)
+    struct RootMfma {
+        MfmaNet mnet;
+        void *bufs[10];
+        int max_k16;
+        std::vector<int> level_job0;
+    } rootm[2];
 };
+using RootMfma = mz_ctx::RootMfma;
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static bool shape_supported(int lanes, int rl) { return lanes == rl || (lanes == 16 && rl < 16) || (lanes == 64 && rl < 64); }
@@ -222,6 +230,8 @@ extern "C" void mz_destroy(mz_ctx *c)
     if (c->net_data_d) (void)hipFree(c->net_data_d);
     for (void *p : c->root_bufs) if (p) (void)hipFree(p);
     for (void *p : c->mnet_bufs) if (p) (void)hipFree(p);
+    for (auto &r : c->rootm)
+        for (void *p : r.bufs) if (p) (void)hipFree(p);
     delete c;
 }
 
@@ -971,14 +981,22 @@ extern "C" int mz_debug_read_path(mz_ctx *c, void *out_h, size_t n_bytes)
 }
 #endif
 
-extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
-                                   const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
-                                   const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
-                                   const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
-                                   const int32_t *io_h)
+// One program in matrix-core layout (muzero_amd/packing.py pack_mfma) checked and uploaded into `slot`: the recurrent
+// program of the searches, or the representation / prediction program of the initial inference.
+struct MfmaSlot {
+    MfmaNet *mnet;
+    void **bufs;                     // [10], see mz_ctx::mnet_bufs
+    int *max_k16;
+    std::vector<int> *level_job0;
+    bool *tile_fits;
+};
+
+static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
+                       const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
+                       const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
+                       const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
+                       const int32_t *io_h)
 {
-    int rc = check_ctx(c, "mz_set_network_mfma");
-    if (rc) return rc;
     if (!steps_h || !sched_h || !wfrag_h || !bias_h || !ctinfo_h || !kidx_h || !io_h || n_steps < 1 ||
         n_sched < 4 || n_levels < 1 || n_jobs < 1 || n_kidx < 1)
         return fail(MZ_ERR_ARG, "mz_set_network_mfma: null/empty program");
@@ -1069,42 +1087,104 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     }
     for (int s2 = 0; s2 < n_steps; s2++)
         if (steps_h[12 * s2] < 0 || steps_h[12 * s2] >= n_levels) return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad level");
-    for (void *&p : c->mnet_bufs) if (p) { (void)hipFree(p); p = nullptr; }
-    c->mnet_level_job0 = job0;
-    c->mnet_max_k16 = 1;
-    for (int s2 = 0; s2 < n_steps; s2++) c->mnet_max_k16 = std::max(c->mnet_max_k16, (int)steps_h[12 * s2 + 2]);
-    c->mnet.sched_ok8 = sched_ok[0]; c->mnet.sched_ok4 = sched_ok[1];
-    c->mnet_tile_fits = ((size_t)stride * 16 * 4 <= 160 * 1024 && sched_ok[1]) ||
+    for (int i = 0; i < 10; i++) if (slot.bufs[i]) { (void)hipFree(slot.bufs[i]); slot.bufs[i] = nullptr; }
+    *slot.level_job0 = job0;
+    *slot.max_k16 = 1;
+    for (int s2 = 0; s2 < n_steps; s2++) *slot.max_k16 = std::max(*slot.max_k16, (int)steps_h[12 * s2 + 2]);
+    slot.mnet->sched_ok8 = sched_ok[0]; slot.mnet->sched_ok4 = sched_ok[1];
+    *slot.tile_fits = ((size_t)stride * 16 * 4 <= 160 * 1024 && sched_ok[1]) ||
                         ((size_t)stride * 32 * 4 <= 160 * 1024 && sched_ok[0]);
-    HIPCHK(hipMalloc(&c->mnet_bufs[9], desc.size() * 4));
-    HIPCHK(hipMemcpy(c->mnet_bufs[9], desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&slot.bufs[9], desc.size() * 4));
+    HIPCHK(hipMemcpy(slot.bufs[9], desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
     const size_t act_rows = ((size_t)c->cfg.max_batch + 31) / 32 * 32;
-    HIPCHK(hipMalloc(&c->mnet_bufs[6], act_rows * stride * 4));
-    HIPCHK(hipMemset(c->mnet_bufs[6], 0, act_rows * stride * 4));
+    HIPCHK(hipMalloc(&slot.bufs[6], act_rows * stride * 4));
+    HIPCHK(hipMemset(slot.bufs[6], 0, act_rows * stride * 4));
     const void *src[4] = {steps_h, sched_h, wfrag_h, bias_h};
     size_t n[4] = {(size_t)n_steps * 12, (size_t)n_sched, (size_t)n_w, (size_t)n_b};
-    const int slot[4] = {0, 1, 3, 4};
+    const int which[4] = {0, 1, 3, 4};
     for (int i = 0; i < 4; i++) {
-        HIPCHK(hipMalloc(&c->mnet_bufs[slot[i]], n[i] * 4));
-        HIPCHK(hipMemcpy(c->mnet_bufs[slot[i]], src[i], n[i] * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&slot.bufs[which[i]], n[i] * 4));
+        HIPCHK(hipMemcpy(slot.bufs[which[i]], src[i], n[i] * 4, hipMemcpyHostToDevice));
     }
-    HIPCHK(hipMalloc(&c->mnet_bufs[7], (size_t)n_jobs * 12));
-    HIPCHK(hipMemcpy(c->mnet_bufs[7], ctinfo_h, (size_t)n_jobs * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->mnet_bufs[8], (size_t)n_kidx * 4));
-    HIPCHK(hipMemcpy(c->mnet_bufs[8], kidx_h, (size_t)n_kidx * 4, hipMemcpyHostToDevice));
-    MfmaNet &m = c->mnet;
-    m.steps = (const int32_t *)c->mnet_bufs[0];
-    const int32_t *sched_d = (const int32_t *)c->mnet_bufs[1];
+    HIPCHK(hipMalloc(&slot.bufs[7], (size_t)n_jobs * 12));
+    HIPCHK(hipMemcpy(slot.bufs[7], ctinfo_h, (size_t)n_jobs * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&slot.bufs[8], (size_t)n_kidx * 4));
+    HIPCHK(hipMemcpy(slot.bufs[8], kidx_h, (size_t)n_kidx * 4, hipMemcpyHostToDevice));
+    MfmaNet &m = *slot.mnet;
+    m.steps = (const int32_t *)slot.bufs[0];
+    const int32_t *sched_d = (const int32_t *)slot.bufs[1];
     m.wstart8 = sched_d + sched_h[0]; m.wdesc8 = sched_d + sched_h[1];
     m.wstart4 = sched_d + sched_h[2]; m.wdesc4 = sched_d + sched_h[3];
     m.w_bytes = (int)(n_w * 4); m.b_bytes = n_b * 4;
-    m.wfrag = (const float *)c->mnet_bufs[3];
-    m.bias = (const float *)c->mnet_bufs[4];
-    m.ctinfo = (const int32_t *)c->mnet_bufs[7]; m.kidx = (const int32_t *)c->mnet_bufs[8];
+    m.wfrag = (const float *)slot.bufs[3];
+    m.bias = (const float *)slot.bufs[4];
+    m.ctinfo = (const int32_t *)slot.bufs[7]; m.kidx = (const int32_t *)slot.bufs[8];
     m.plane_major = plane_major ? 1 : 0;
     m.n_steps = n_steps; m.n_levels = n_levels; m.stride = stride;
     memcpy(m.io, io_h, sizeof m.io);
     return MZ_OK;
+}
+
+
+extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
+                                   const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
+                                   const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
+                                   const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
+                                   const int32_t *io_h)
+{
+    int rc = check_ctx(c, "mz_set_network_mfma");
+    if (rc) return rc;
+    const MfmaSlot slot{&c->mnet, c->mnet_bufs, &c->mnet_max_k16, &c->mnet_level_job0, &c->mnet_tile_fits};
+    return upload_mfma(c, slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
+                       kidx_h, n_kidx, stride, plane_major, io_h);
+}
+
+extern "C" int mz_set_root_network_mfma(mz_ctx *c, int32_t part, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
+                                        const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
+                                        const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
+                                        const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
+                                        const int32_t *io_h)
+{
+    int rc = check_ctx(c, "mz_set_root_network_mfma");
+    if (rc) return rc;
+    if (part != 0 && part != 1) return fail(MZ_ERR_ARG, "mz_set_root_network_mfma: part is 0 (representation) or 1 (prediction)");
+    RootMfma &r = c->rootm[part];
+    bool unused = false;
+    const MfmaSlot slot{&r.mnet, r.bufs, &r.max_k16, &r.level_job0, &unused};
+    return upload_mfma(c, slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
+                       kidx_h, n_kidx, stride, plane_major, io_h);
+}
+
+// network.py:86-103 for B observations through the two uploaded root programs, level by level on the matrix cores.
+extern "C" int mz_initial_inference_mfma(mz_ctx *c, int32_t B, const float *obs, float *out_logits, float *out_hidden,
+                                         double *out_value, void *stream)
+{
+    int rc = check_ctx(c, "mz_initial_inference_mfma");
+    if (rc) return rc;
+    if (B < 1 || B > c->cfg.max_batch) return fail(MZ_ERR_ARG, "mz_initial_inference_mfma: B outside 1..max_batch");
+    if (!obs || !out_logits || !out_hidden || !out_value) return fail(MZ_ERR_ARG, "mz_initial_inference_mfma: null argument");
+    RootMfma &rep = c->rootm[0], &pred = c->rootm[1];
+    if (!rep.mnet.steps || !pred.mnet.steps)
+        return fail(MZ_ERR_STATE, "mz_initial_inference_mfma: upload both root programs first (mz_set_root_network_mfma)");
+    const hipStream_t st = (hipStream_t)stream;
+    auto run_levels = [&](RootMfma &r) -> int {
+        float *acts = (float *)r.bufs[6];
+        const int32_t *desc = (const int32_t *)r.bufs[9];
+        for (int l = 0; l < r.mnet.n_levels; l++) {
+            const int j0 = r.level_job0[l], nb = r.level_job0[l + 1] - j0;
+            if (nb < 1) continue;
+            HIPCHK(launch_net_level_rows((unsigned)nb, (unsigned)((B + 31) / 32), r.max_k16, st, r.mnet,
+                                         desc + MZ_LVL_DESC * j0, acts, 0, l));
+        }
+        return MZ_OK;
+    };
+    launch_root_stage_obs(st, (int)B, rep.mnet, obs, (float *)rep.bufs[6]);
+    if ((rc = run_levels(rep))) return rc;
+    launch_root_hidden(st, (int)B, rep.mnet, (const float *)rep.bufs[6], out_hidden);
+    launch_root_stage_hidden(st, (int)B, pred.mnet, out_hidden, (float *)pred.bufs[6]);
+    if ((rc = run_levels(pred))) return rc;
+    launch_root_outputs(st, (int)B, pred.mnet, (const float *)pred.bufs[6], out_logits, out_value);
+    return launch_status("mz_initial_inference_mfma");
 }
 
 // Staging of one batched leaf evaluation: activations of the per-level path ([rows][stride] floats, rows = the batch

@@ -65,6 +65,26 @@ void launch_stage_inputs(hipStream_t st, const Dev &d, const MfmaNet &net, float
     hipLaunchKernelGGL(k_stage_inputs, dim3((d.B + 3) / 4), dim3(256), 0, st, d, net, acts);
 }
 
+void launch_root_stage_obs(hipStream_t st, int B, const MfmaNet &rep, const float *obs, float *acts)
+{
+    hipLaunchKernelGGL(k_root_stage_obs, dim3((B + 3) / 4), dim3(256), 0, st, B, rep, obs, acts);
+}
+
+void launch_root_hidden(hipStream_t st, int B, const MfmaNet &rep, const float *acts, float *out_hidden)
+{
+    hipLaunchKernelGGL(k_root_hidden, dim3((B + 3) / 4), dim3(256), 0, st, B, rep, acts, out_hidden);
+}
+
+void launch_root_stage_hidden(hipStream_t st, int B, const MfmaNet &pred, const float *hidden, float *acts)
+{
+    hipLaunchKernelGGL(k_root_stage_hidden, dim3((B + 3) / 4), dim3(256), 0, st, B, pred, hidden, acts);
+}
+
+void launch_root_outputs(hipStream_t st, int B, const MfmaNet &pred, const float *acts, float *out_logits, double *out_value)
+{
+    hipLaunchKernelGGL(k_root_outputs, dim3((B + 3) / 4), dim3(256), 0, st, B, pred, acts, out_logits, out_value);
+}
+
 bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, int t_first, int t_end,
                                int leaf, float *acts, const double *noise, int noise_max_calls, int select_next)
 {

@@ -53,6 +53,11 @@ static_assert(MZ_LVL_DESC >= 10 + 3 * MZ_LVL_WAVES, "a block descriptor holds th
 hipError_t launch_net_level_rows(unsigned n_jobs, unsigned n_row_tiles, int max_k16, hipStream_t st, const MfmaNet &net,
                                  const int32_t *desc, float *acts, int row_first, int level);
 void launch_stage_inputs(hipStream_t st, const Dev &d, const MfmaNet &net, float *acts);
+// initial inference on the level kernels: observations in, scaled hidden states across, logits and values out
+void launch_root_stage_obs(hipStream_t st, int B, const MfmaNet &rep, const float *obs, float *acts);
+void launch_root_hidden(hipStream_t st, int B, const MfmaNet &rep, const float *acts, float *out_hidden);
+void launch_root_stage_hidden(hipStream_t st, int B, const MfmaNet &pred, const float *hidden, float *acts);
+void launch_root_outputs(hipStream_t st, int B, const MfmaNet &pred, const float *acts, float *out_logits, double *out_value);
 bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, int t_first, int t_end,
                                int leaf, float *acts, const double *noise, int noise_max_calls, int select_next);
 

@@ -340,11 +340,11 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBuf
 // SUP = lanes that reduce the supports: the float32 sums depend on it, so every path that must agree bit for
 // bit with the 16-lane groups of the tile-resident kernels uses 16 (each 16-lane row of a wider group then
 // computes the same thing).
-template <int LANES = 16, int SUP = LANES>
-__device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *row, int a, float *hidden_dst,
-                                               double *value, double *reward)
+// The hidden-state half of the epilogue: the raw state at io[2] of the row, scaled per group, into `hidden_dst`.
+template <int LANES>
+__device__ __forceinline__ void tile_hidden_out(const MfmaNet &net, const float *row, int a, float *hidden_dst)
 {
-    const int H = net.io[6], sup = net.io[9], ngroups = net.io[10];
+    const int H = net.io[6], ngroups = net.io[10];
     const int per = H / ngroups;
     if (ngroups >= 8) {  // many small groups (board planes): one lane per group
         const int sj = net.plane_major ? ngroups : 1, sg = net.plane_major ? 1 : per;  // element (g, j) at g * sg + j * sj
@@ -358,6 +358,14 @@ __device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *r
     } else {
         minmax_to<LANES>(row + net.io[2], H, ngroups, a, hidden_dst, nullptr);
     }
+}
+
+template <int LANES = 16, int SUP = LANES>
+__device__ __forceinline__ void tile_epilogue(const MfmaNet &net, const float *row, int a, float *hidden_dst,
+                                               double *value, double *reward)
+{
+    const int sup = net.io[9];
+    tile_hidden_out<LANES>(net, row, a, hidden_dst);
     support_to_scalar2<SUP>(row + net.io[5], row + net.io[3], sup, a % SUP, value, reward);
 }
 
@@ -429,6 +437,51 @@ __global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int le
     else tile_epilogue<LANES, LANES>(net, row, a, hidden_dst, &value, &reward);
     for (int j = a; j < A; j += LANES) out_logits[(long long)t * A + j] = row[net.io[4] + j];
     if (a == 0) { out_value[t] = value; out_reward[t] = reward; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// initial_inference (network.py:86-103) on the level kernels: the representation program turns observations into raw
+// hidden states, which are scaled per group (utils/network_utils.py:132-158) and handed to the prediction program;
+// policy logits and the value (support_to_scalar, utils/network_utils.py:75-96) come out of its row.  One wave per
+// root; the matrix work in between is k_net_level_rows on each program's own activation rows.
+
+// observations [B][io[11]] into the rows of the representation program (its input tensor starts at io[0])
+__global__ __launch_bounds__(256) void k_root_stage_obs(int B, MfmaNet net, const float *obs, float *acts)
+{
+    const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
+    if (t >= B) return;
+    const int n = net.io[11];
+    float *row = acts + (long long)t * net.stride + net.io[0];
+    for (int j = a; j < n; j += 64) row[j] = obs[(long long)t * n + j];
+}
+
+// the scaled hidden state of every root: out of the representation program's row into out_hidden [B][H]
+__global__ __launch_bounds__(256) void k_root_hidden(int B, MfmaNet rep, const float *acts, float *out_hidden)
+{
+    const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
+    if (t >= B) return;
+    tile_hidden_out<64>(rep, acts + (long long)t * rep.stride, a, out_hidden + (long long)t * rep.io[6]);
+}
+
+// ... and into the rows of the prediction program (io[8] of that program is 0: no action beside the state)
+__global__ __launch_bounds__(256) void k_root_stage_hidden(int B, MfmaNet pred, const float *hidden, float *acts)
+{
+    const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
+    if (t >= B) return;
+    tile_stage_inputs<64>(pred, acts + (long long)t * pred.stride, hidden + (long long)t * pred.io[6], 0, a);
+}
+
+// policy logits and value of every root out of the prediction program's row
+__global__ __launch_bounds__(256) void k_root_outputs(int B, MfmaNet pred, const float *acts, float *out_logits, double *out_value)
+{
+    const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
+    if (t >= B) return;
+    const int A = pred.io[7];
+    const float *row = acts + (long long)t * pred.stride;
+    for (int j = a; j < A; j += 64) out_logits[(long long)t * A + j] = row[pred.io[4] + j];
+    double value, twin;
+    support_to_scalar2<64>(row + pred.io[5], row + pred.io[5], pred.io[9], a, &value, &twin);
+    if (a == 0) out_value[t] = value;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -56,7 +56,7 @@ class MzMoveLog(C.Structure):
 ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_set_seed', 'mz_check', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
-           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_expand_backup_net', 'mz_expand_backup_net_static', 'mz_act_env_step', 'mz_act_env_step_log', 'mz_log_count_games', 'mz_log_list_games', 'mz_tree_export',
+           'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_set_root_network_mfma', 'mz_initial_inference_mfma', 'mz_expand_backup_net', 'mz_expand_backup_net_static', 'mz_act_env_step', 'mz_act_env_step_log', 'mz_log_count_games', 'mz_log_list_games', 'mz_tree_export',
            'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
@@ -90,6 +90,8 @@ def lib():
         L.mz_set_network.argtypes = [vp, vp, i32, vp, i32, vp]
         L.mz_set_root_network.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp]
         L.mz_set_network_mfma.argtypes = [vp, vp, i32, i32, vp, i32, vp, C.c_int64, vp, i32, vp, i32, vp, i32, i32, i32, vp]
+        L.mz_set_root_network_mfma.argtypes = [vp, i32, vp, i32, i32, vp, i32, vp, C.c_int64, vp, i32, vp, i32, vp, i32, i32, i32, vp]
+        L.mz_initial_inference_mfma.argtypes = [vp, i32, vp, vp, vp, vp, vp]
         L.mz_expand_backup_net.argtypes = [vp, i32, vp, i32, vp]
         L.mz_expand_backup_net_static.argtypes = [vp, i32, vp, i32, vp]
         L.mz_act_env_step.argtypes = [vp, C.POINTER(MzEnvState), f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -323,6 +325,30 @@ class SearchEngine:
                                          C.c_int64(pm.wfrag.size), vp(pm.bias), int(pm.bias.size),
                                          vp(pm.ctinfo), pm.ctinfo.size // 3, vp(pm.kidx), int(pm.kidx.size),
                                          int(pm.stride), int(pm.plane_major), vp(io)))
+
+    def set_root_network_mfma(self, rep, pred):
+        """Uploads the representation and prediction programs of the initial inference in matrix-core layout
+        (muzero_amd.packing.pack_root_network_mfma: two (program, io) pairs)."""
+        self._root_mfma_keep = (rep, pred)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        for part, (pm, io) in enumerate((rep, pred)):
+            _check(lib().mz_set_root_network_mfma(self._ctx, part, vp(pm.steps), pm.steps.size // 12, int(pm.n_levels),
+                                                  vp(pm.sched), int(pm.sched.size), vp(pm.wfrag),
+                                                  C.c_int64(pm.wfrag.size), vp(pm.bias), int(pm.bias.size),
+                                                  vp(pm.ctinfo), pm.ctinfo.size // 3, vp(pm.kidx), int(pm.kidx.size),
+                                                  int(pm.stride), int(pm.plane_major), vp(io)))
+
+    def initial_inference_mfma(self, obs):
+        """network.initial_inference (network.py:86-103) of B observations on the device, through the programs given to
+        set_root_network_mfma: (policy logits f32[B, A], hidden states f32[B, H], values f64[B]), device tensors."""
+        obs = self._dev(obs, torch.float32)
+        B = obs.shape[0]
+        obs = obs.reshape(B, -1).contiguous()
+        logits = torch.empty((B, self.A), dtype=torch.float32, device=self.device)
+        hidden = torch.empty((B, self.H), dtype=torch.float32, device=self.device)
+        value = torch.empty(B, dtype=torch.float64, device=self.device)
+        _check(lib().mz_initial_inference_mfma(self._ctx, B, _ptr(obs), _ptr(logits), _ptr(hidden), _ptr(value), _stream()))
+        return logits, hidden, value
 
     def expand_backup_net(self, select_next: bool = False, noise=None, static_scratch: bool = False):
         """Leaf evaluation on the matrix cores + expansion + backup for the pending selection; with

@@ -101,8 +101,8 @@ class MCTS:
     @staticmethod
     def _lowered_plan(network, A: int):
         """How a lowered network (muzero_amd.network.MuZeroDenseNetwork) is evaluated inside the search
-        kernels: ('fused', PackedNetwork) when its weights fit in LDS, ('mfma', (PackedMfma, io)) for
-        larger ones with at most 16 actions, None otherwise (or for any other network object).
+        kernels: ('fused', PackedNetwork) when its weights fit in LDS, ('mfma', (PackedMfma, io), the two root
+        programs) for larger ones with at most 16 actions, None otherwise (or for any other network object).
         Packings are cached on the network and rebuilt when its weights change."""
         if not (hasattr(network, 'dyn') and hasattr(network, 'pred') and hasattr(network, 'rep')):
             return None
@@ -110,7 +110,7 @@ class MCTS:
         cached = getattr(network, '_mz_plan', None)
         if cached is not None and cached[0] == stamp:
             return cached[1]
-        from muzero_amd.packing import pack_network, pack_network_mfma
+        from muzero_amd.packing import pack_network, pack_network_mfma, pack_root_network_mfma
         plan = None
         packed = pack_network(network)
         if max(p.weight_bytes() for p in (packed.recurrent, packed.represent, packed.predict)) <= 48 * 1024:
@@ -118,7 +118,7 @@ class MCTS:
         elif A <= 16:
             pm, io = pack_network_mfma(network)
             if pm.stride * 32 * 4 + 4096 <= 160 * 1024:
-                plan = ('mfma', (pm, io))
+                plan = ('mfma', (pm, io), pack_root_network_mfma(network))
         network._mz_plan = (stamp, plan)
         return plan
 
@@ -133,8 +133,10 @@ class MCTS:
         network = self._auto_lower(network)
         noise_mode = _engine.NOISE_BUFFER if (stream_noise and not gumbel) else _engine.NOISE_COUNTER
         plan = self._lowered_plan(network, A)
-        if plan is not None and plan[0] == 'fused':
-            H, logits, hidden, value = plan[1].H, None, None, None   # the root is evaluated on the device too
+        if plan is not None:
+            # the root is evaluated on the device too: inside the first launch (fused) or level by level on the
+            # matrix cores (mz_initial_inference_mfma)
+            H, logits, hidden, value = int(network.H), None, None, None
         else:
             with torch.no_grad():
                 logits, hidden, value = network.initial_inference(obs)
@@ -147,7 +149,10 @@ class MCTS:
                 eng.set_network(plan[1])
             else:
                 eng.set_network_mfma(*plan[1])
+                eng.set_root_network_mfma(*plan[2])
             eng._plan_of = (id(network), id(plan))
+        if plan is not None and plan[0] == 'mfma':
+            logits, hidden, value = eng.initial_inference_mfma(obs.reshape(B, -1))
         g = dirichlet = u_pre = None
         if gumbel:
             g = np.stack([np.random.gumbel(size=A) for _ in range(B)])

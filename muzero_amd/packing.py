@@ -400,3 +400,35 @@ def pack_network_mfma(net, plane_major=None):
                      pm.slots['policy_logits'], pm.slots['value_logits'], H, net.A, asz,
                      2 * net.support_limit + 1, net.norm_groups, net.obs_size], np.int32)
     return pm, io
+
+
+def pack_root_network_mfma(net, plane_major=None):
+    """The two programs of the initial inference (network.py:86-103) of a lowered network in MFMA layout, each with an
+    io vector shaped like PackedNetwork.io(): (representation program, io), (prediction program, io).  The
+    representation program reads the observation at io[0] and leaves the raw hidden state at io[2]; the prediction
+    program reads the scaled hidden state at io[0] (io[8] = 0: no action beside it) and leaves policy logits at io[4],
+    value logits at io[5].  Board networks keep their feature maps cell-major as in pack_network_mfma."""
+    H = net.H
+    C = int(net.norm_groups)
+    can = getattr(net, 'kind', '') == 'resnet' and C % 16 == 0 and H % C == 0
+    if plane_major is None:
+        plane_major = can
+    if plane_major and not can:
+        raise ValueError('plane-major storage needs a board network whose channel count is a multiple of 16')
+    p = plane_major_permutation(C, H // C) if plane_major else None
+    out = []
+    for steps, inputs, keep in ((list(net.rep.steps), {'obs': net.obs_size}, ('hidden_raw',)),
+                                (list(net.pred.steps), {'hidden': H}, ('policy_logits', 'value_logits'))):
+        perms = {}
+        if plane_major:
+            perms = {s.out: p for s in steps if int(s.W.shape[0]) == H}
+            if 'hidden' in inputs:
+                perms['hidden'] = p
+        pm = pack_mfma(steps, inputs, None, keep=keep, perms=perms)
+        pm.plane_major = int(bool(plane_major))
+        first = pm.slots['obs'] if 'obs' in inputs else pm.slots['hidden']
+        io = np.asarray([first, first + (H if 'hidden' in inputs else net.obs_size), pm.slots.get('hidden_raw', 0), 0,
+                         pm.slots.get('policy_logits', 0), pm.slots.get('value_logits', 0), H, net.A, 0,
+                         2 * net.support_limit + 1, net.norm_groups, net.obs_size], np.int32)
+        out.append((pm, io))
+    return out[0], out[1]

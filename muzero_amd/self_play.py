@@ -91,7 +91,7 @@ class BatchedSelfPlay:
         self._noise_mode, self._seed = noise_mode, seed
         H = None
         if hasattr(network, 'recurrent_flat'):
-            from .packing import pack_network, pack_network_mfma
+            from .packing import pack_network, pack_network_mfma, pack_root_network_mfma
             H = network.H
             packed = pack_network(network)
             self.engine = _engine.SearchEngine(config, H, B, seed=seed, noise_mode=noise_mode, device=self.device)
@@ -104,6 +104,7 @@ class BatchedSelfPlay:
             else:
                 network.to(self.device)
                 self.engine.set_network_mfma(*pack_network_mfma(network))
+                self.engine.set_root_network_mfma(*pack_root_network_mfma(network))   # the roots, too, on the device
                 self.mode = 'mfma'
         else:
             self.engine = None  # created on the first step, once the hidden size is known
@@ -157,7 +158,7 @@ class BatchedSelfPlay:
             net = self.network
             with torch.no_grad():
                 if self.mode == 'mfma':
-                    lg, hid, val = net.initial_flat(e.search_obs)
+                    lg, hid, val = eng.initial_inference_mfma(e.search_obs)
                 else:
                     shape = getattr(net, 'observation_shape', None)
                     obs = e.search_obs.cpu().reshape(self.B, *shape) if shape else e.search_obs.cpu()
