@@ -383,7 +383,7 @@ def main():
         'recording': ({'where': 'device move log, written by k_act_env', 'games_recorded_rank0': games_recorded,
                        'moves_recorded_rank0': B * n_steps} if leaf == 'selfplay' else None),
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation' if A > 16 else 'k_search_mfma'), 'mfma_step': ('k_stage_inputs + k_net_level_rows x levels + k_net_epilogue + k_backup_select, per simulation' if A > 16 else 'k_net_step+k_backup_select'), 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the host, k_search_mfma, host copies)',
+                                'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation' if A > 16 else 'k_search_mfma'), 'mfma_step': ('k_stage_inputs + k_net_level_rows x levels + k_net_epilogue + k_backup_select, per simulation' if A > 16 else 'k_net_step+k_backup_select'), 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the level kernels, k_search_mfma, host copies)',
                                 'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
