@@ -72,7 +72,8 @@ void launch_root_stage_obs(hipStream_t st, int B, const MfmaNet &rep, const floa
 
 void launch_root_hidden(hipStream_t st, int B, const MfmaNet &rep, const float *acts, float *out_hidden)
 {
-    hipLaunchKernelGGL(k_root_hidden, dim3((B + 3) / 4), dim3(256), 0, st, B, rep, acts, out_hidden);
+    if (rep.io[10] >= 8) hipLaunchKernelGGL(k_root_hidden<16>, dim3((B + 15) / 16), dim3(256), 0, st, B, rep, acts, out_hidden);
+    else hipLaunchKernelGGL(k_root_hidden<64>, dim3((B + 3) / 4), dim3(256), 0, st, B, rep, acts, out_hidden);
 }
 
 void launch_root_stage_hidden(hipStream_t st, int B, const MfmaNet &pred, const float *hidden, float *acts)

@@ -456,11 +456,13 @@ __global__ __launch_bounds__(256) void k_root_stage_obs(int B, MfmaNet net, cons
 }
 
 // the scaled hidden state of every root: out of the representation program's row into out_hidden [B][H]
+// (LANES per root: 16 when the state is scaled per board plane - one lane per plane -, else a whole wave)
+template <int LANES>
 __global__ __launch_bounds__(256) void k_root_hidden(int B, MfmaNet rep, const float *acts, float *out_hidden)
 {
-    const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
+    const int t = (int)(blockIdx.x * (256 / LANES) + threadIdx.x / LANES), a = threadIdx.x % LANES;
     if (t >= B) return;
-    tile_hidden_out<64>(rep, acts + (long long)t * rep.stride, a, out_hidden + (long long)t * rep.io[6]);
+    tile_hidden_out<LANES>(rep, acts + (long long)t * rep.stride, a, out_hidden + (long long)t * rep.io[6]);
 }
 
 // ... and into the rows of the prediction program (io[8] of that program is 0: no action beside the state)
