@@ -1,6 +1,6 @@
 """Soak test (not part of the suite): leaves evaluated on the matrix cores, on random MLP and ResNet
 networks and batch sizes.  (1) One network step against the same network run by torch (1e-5; hidden
-1e-4); (2) the stepped, backup+selection-fused, whole-search and layer-by-layer launch modes must give the
+1e-4); (0) the initial inference on the device against torch (same tolerances); (2) the stepped, backup+selection-fused, whole-search and layer-by-layer launch modes must give the
 same trees bit for bit (long supports on the layer-by-layer path excepted: another float32 sum order);
 (3) whole searches agree with torch-evaluated leaves on (nearly) every tree.  Boards start at 3x3: on
 2x2 boards the reference's per-plane min-max scaling (4 cells per plane) amplifies a one-ulp difference in a
@@ -58,6 +58,21 @@ for trial in range(TRIALS):
     g = rng.gumbel(size=(B, A)) if gumbel else None
     di = None if gumbel else rng.dirichlet([0.25] * A, size=B)
     ok, results = True, {}
+    # (0) the initial inference on the device (representation program, hidden-state scaling, prediction program,
+    # support_to_scalar) against the same network run by torch
+    try:
+        from muzero_amd.packing import pack_root_network_mfma
+        eng = SearchEngine(cfg, net.H, B, seed=trial)
+        eng.set_root_network_mfma(*pack_root_network_mfma(net))
+        rl, rh, rv = eng.initial_inference_mfma(obs.reshape(B, -1))
+        errs = (np.abs(rl.cpu().numpy() - logits).max(), np.abs(rh.cpu().numpy() - hidden).max() / 10,
+                np.abs(rv.cpu().numpy() - value).max() / max(1.0, L / 10))
+        eng.close()
+        if not max(errs) <= 1e-5:
+            ok = False
+            print('ROOT INFERENCE DIFFERS trial', trial, errs, desc, flush=True)
+    except ValueError as e:
+        print('  root inference not served:', e, flush=True)
     for mode in ORDER:
         print('  trial', trial, mode, desc, flush=True)
         os.environ['MZ_NET_PATH'] = 'level' if mode == 'mfma_level' else 'tile'
