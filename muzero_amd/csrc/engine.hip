@@ -58,6 +58,14 @@ struct mz_ctx {
     int mnet_max_k16;                  // widest layer input in blocks of 16 floats
     std::vector<int> mnet_level_job0;  // first block of each level in the job table (+ total at the end)
     bool mnet_tile_fits;               // a 16-tree activation tile fits in LDS (tile-resident kernels usable)
+    // host copies of the uploaded program's tables, from which the chained search's work lists are made, and that
+    // search's device buffers: segment table + ranges (for `chain_G` workgroups per cluster), tagged activations
+    std::vector<int32_t> mnet_steps_h, mnet_ctinfo_h, mnet_kidx_h;
+    int chain_G, chain_n_seg, chain_kk_max, chain_ok;   // chain_ok: -1 not examined, 0 not servable, 1 servable
+    int chain_in_n, chain_out_phase[4];
+    std::string chain_why;                              // why the chained search does not serve this network
+    void *chain_tab, *chain_acts2;
+    size_t chain_acts2_bytes;
     float *leaf_logits; // [max_batch][A] outputs of the batched leaf evaluation
     double *leaf_value, *leaf_reward;
     // representation and prediction programs of the initial inference in matrix-core layout (mz_set_root_network_mfma)
@@ -143,6 +151,8 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     memset(&c->net, 0, sizeof c->net); c->net_scratch = 0; c->net_small = false; c->net_tiny = false; c->net_meta_d = c->net_data_d = nullptr;
     memset(&c->root, 0, sizeof c->root); memset(c->root_bufs, 0, sizeof c->root_bufs);
     memset(&c->mnet, 0, sizeof c->mnet); memset(c->mnet_bufs, 0, sizeof c->mnet_bufs);
+    c->chain_G = 0; c->chain_n_seg = 0; c->chain_kk_max = 0; c->chain_ok = -1; c->chain_in_n = 0;
+    c->chain_tab = c->chain_acts2 = nullptr; c->chain_acts2_bytes = 0;
     Dev &d = c->d;
     memset(&d, 0, sizeof d);
     Layout &L = d.L;
@@ -230,6 +240,8 @@ extern "C" void mz_destroy(mz_ctx *c)
     if (c->net_data_d) (void)hipFree(c->net_data_d);
     for (void *p : c->root_bufs) if (p) (void)hipFree(p);
     for (void *p : c->mnet_bufs) if (p) (void)hipFree(p);
+    if (c->chain_tab) (void)hipFree(c->chain_tab);
+    if (c->chain_acts2) (void)hipFree(c->chain_acts2);
     for (auto &r : c->rootm)
         for (void *p : r.bufs) if (p) (void)hipFree(p);
     delete c;
@@ -433,6 +445,159 @@ static int search_by_level(mz_ctx *c, int n_sims, const double *noise, int32_t n
     return MZ_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same searches in ONE launch (search_chain.h): clusters of G workgroups run the network level by level for tiles
+// of 16 trees while tree waves of the same workgroups finish and restart the trees; data crosses workgroups as tagged
+// granules.  chain_examine decides once per uploaded program whether that kernel serves it and says why not.
+static int chain_examine(mz_ctx *c)
+{
+    if (c->chain_ok >= 0) return c->chain_ok;
+    c->chain_ok = 0;
+    const MfmaNet &net = c->mnet;
+    const std::vector<int32_t> &st = c->mnet_steps_h;
+    auto no = [&](const char *why) { c->chain_why = why; return 0; };
+    if (st.empty()) return no("no program");
+    if (!search_chain_built(c->rl)) return no("the kernel is not built for this action count");
+    const int n_steps = net.n_steps, H = net.io[6], asz = net.io[8];
+    const int in_lo = net.io[0], in_n = (H + asz + 15) / 16 * 16;
+    if (net.io[1] != in_lo + H) return no("the action does not follow the hidden state in the activation row");
+    if (in_lo % 4 || in_lo + in_n > net.stride) return no("network inputs not 16-byte aligned inside the row");
+    // every tensor in a place of its own, whole 16-float tiles: a column tile is written whole, and nothing orders a
+    // writer behind the readers of whatever shared its place (a launch boundary does that for the level kernels)
+    struct Span { int lo, hi, phase; };
+    std::vector<Span> spans{{in_lo, in_lo + in_n, 0}};
+    int kk_max = 16;
+    std::vector<int> per_level(net.n_levels, 0);
+    for (int s = 0; s < n_steps; s++) {
+        const int32_t *q = &st[12 * s];
+        if (q[4] % 16) return no("a layer's outputs do not start on a multiple of 16 floats");
+        if (q[3] % 4) return no("a layer's inputs are not 16-byte aligned");
+        if (q[5] >= 0 && q[5] % 16) return no("a residual input does not start on a multiple of 16 floats");
+        spans.push_back({q[4], q[4] + q[9] * 16, q[0] + 1});
+        kk_max = std::max(kk_max, q[2] * 16);
+        per_level[q[0]] += q[9];
+    }
+    for (size_t i = 0; i < spans.size(); i++)
+        for (size_t j = i + 1; j < spans.size(); j++)
+            if (spans[i].lo < spans[j].hi && spans[j].lo < spans[i].hi)
+                return no("two tensors share a place in the activation row (pack the network without reuse)");
+    for (int l = 0; l < net.n_levels; l++) if (per_level[l] < 1) return no("a level without layers");
+    auto producer = [&](int off, int width) -> int {   // phase that writes [off, off + width)
+        for (const Span &sp : spans) if (off >= sp.lo && off + width <= sp.hi) return sp.phase;
+        return -1;
+    };
+    for (int s = 0; s < n_steps; s++) {
+        const int32_t *q = &st[12 * s];
+        const int pi = producer(q[3], q[2] * 16), ps = q[5] >= 0 ? producer(q[5], q[9] * 16) : 0;
+        if (pi < 0 || pi > q[0] || ps < 0 || ps > q[0]) return no("a layer reads what no earlier phase writes whole");
+    }
+    const int outs[4] = {net.io[2], net.io[3], net.io[4], net.io[5]};
+    const int outn[4] = {H, net.io[9], net.io[7], net.io[9]};
+    for (int k = 0; k < 4; k++) {
+        c->chain_out_phase[k] = producer(outs[k], (outn[k] + 15) / 16 * 16);
+        if (c->chain_out_phase[k] < 1) return no("a network output is not a whole layer output");
+    }
+    if (search_chain_lds(net, kk_max, c->cfg.gumbel != 0) > 160 * 1024) return no("staging and tree rows exceed LDS");
+    const size_t rows = ((size_t)c->cfg.max_batch + 31) / 32 * 32;
+    if (rows * net.stride * 8 >= ((size_t)1 << 31)) return no("tagged activations exceed 2 GiB");
+    c->chain_kk_max = kk_max; c->chain_in_n = in_n;
+    c->chain_why.clear();
+    return c->chain_ok = 1;
+}
+
+// Work lists for clusters of G workgroups: per level the column tiles of its layers, in order, are dealt in equal
+// shares; a share is cut into segments of at most 8 column tiles of one layer.
+static int chain_prepare(mz_ctx *c, int G)
+{
+    if (c->chain_G == G && c->chain_tab) return MZ_OK;
+    const MfmaNet &net = c->mnet;
+    const std::vector<int32_t> &st = c->mnet_steps_h, &cti = c->mnet_ctinfo_h, &kidx = c->mnet_kidx_h;
+    const int H = net.io[6], asz = net.io[8], in_lo = net.io[0], in_n = c->chain_in_n;
+    auto producer = [&](int off) -> int {
+        if (off >= in_lo && off < in_lo + in_n) return 0;
+        for (int s = 0; s < net.n_steps; s++)
+            if (off >= st[12 * s + 4] && off < st[12 * s + 4] + st[12 * s + 9] * 16) return st[12 * s] + 1;
+        return 0;
+    };
+    (void)H; (void)asz;
+    std::vector<int32_t> seg, range;
+    for (int l = 0; l < net.n_levels; l++) {
+        std::vector<std::pair<int, int>> tiles;   // (step, column tile)
+        for (int s = 0; s < net.n_steps; s++)
+            if (st[12 * s] == l)
+                for (int ct = 0; ct < st[12 * s + 9]; ct++) tiles.push_back({s, ct});
+        const int total = (int)tiles.size(), share = (total + G - 1) / G;
+        int pos = 0;
+        for (int m = 0; m < G; m++) {
+            range.push_back((int)(seg.size() / MZ_CH_SEG));
+            const int end = std::min(total, pos + share);
+            while (pos < end) {
+                const int s = tiles[pos].first, ct0 = tiles[pos].second;
+                int n = 1;
+                while (n < 8 && pos + n < end && tiles[pos + n].first == s) n++;
+                const int32_t *q = &st[12 * s];
+                int32_t d[MZ_CH_SEG] = {q[2] * 16, q[3], q[4] + 16 * ct0, q[5] >= 0 ? q[5] + 16 * ct0 : -1, q[6], q[8] + 16 * ct0,
+                                        n, 1, producer(q[3]), q[5] >= 0 ? producer(q[5]) : 0, l + 1, 0};
+                for (int w = 0; w < n; w++) {
+                    const int32_t *cj = &cti[3 * (q[10] + ct0 + w)];
+                    d[12 + 3 * w] = cj[0] * 4; d[13 + 3 * w] = cj[2]; d[14 + 3 * w] = cj[1];
+                    for (int i = 0; i < cj[2]; i++) if (kidx[cj[1] + i] != i) d[7] = 0;
+                }
+                seg.insert(seg.end(), d, d + MZ_CH_SEG);
+                pos += n;
+            }
+        }
+        range.push_back((int)(seg.size() / MZ_CH_SEG));
+    }
+    if (c->chain_tab) { (void)hipFree(c->chain_tab); c->chain_tab = nullptr; }
+    c->chain_G = 0;
+    c->chain_n_seg = (int)(seg.size() / MZ_CH_SEG);
+    std::vector<int32_t> tab(seg);
+    tab.insert(tab.end(), range.begin(), range.end());
+    HIPCHK(hipMalloc(&c->chain_tab, tab.size() * 4));
+    HIPCHK(hipMemcpy(c->chain_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    if (!c->chain_acts2) {
+        const size_t rows = ((size_t)c->cfg.max_batch + 31) / 32 * 32;
+        c->chain_acts2_bytes = rows * net.stride * 8;
+        HIPCHK(hipMalloc(&c->chain_acts2, c->chain_acts2_bytes));
+    }
+    c->chain_G = G;
+    return MZ_OK;
+}
+
+static int search_chained(mz_ctx *c, int n_sims, const double *noise, int32_t noise_max_calls, hipStream_t stream)
+{
+    int n_cu = 0;
+    HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device));
+    const int n_tiles = (c->B + MZ_CH_TM - 1) / MZ_CH_TM;
+    // workgroups per cluster: 8, more when the batch has fewer tiles than clusters (every CU should have work)
+    int G = 8;
+    while (G < 32 && n_cu / (2 * G) >= n_tiles) G *= 2;
+    if (const char *e = getenv("MZ_CHAIN_G")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) G = v; }
+    if (n_cu < G) return fail(MZ_ERR_HIP, "mz_search_run: fewer compute units than one cluster of the chained search needs");
+    int rc = chain_prepare(c, G);
+    if (rc) return rc;
+    ChainArgs ca{};
+    ca.seg = (const int32_t *)c->chain_tab;
+    ca.blk_range = ca.seg + (size_t)c->chain_n_seg * MZ_CH_SEG;
+    ca.acts2 = (float *)c->chain_acts2;
+    ca.acts2_bytes = (unsigned)c->chain_acts2_bytes;
+    ca.G = G; ca.n_clusters = std::min(n_cu / G, n_tiles); ca.n_tiles = n_tiles;
+    ca.kk_max = c->chain_kk_max; ca.in_lo = c->mnet.io[0]; ca.in_n = c->chain_in_n;
+    for (int k = 0; k < 4; k++) ca.out_phase[k] = c->chain_out_phase[k];
+    ca.first_leaf = c->n_expanded + 1; ca.n_sims = n_sims;
+    ca.noise = noise; ca.noise_max_calls = noise_max_calls;
+    double ms = 250.0;
+    if (const char *e = getenv("MZ_CHAIN_TIMEOUT_MS")) { const double v = atof(e); if (v >= 1.0 && v <= 10000.0) ms = v; }
+    ca.timeout = (long long)(ms * 1e5);   // the clock the kernel reads ticks at 100 MHz
+    // tags count from 1 within a launch: whatever the last search left must not look like data
+    HIPCHK(hipMemsetAsync(c->chain_acts2, 0, (size_t)n_tiles * MZ_CH_TM * c->mnet.stride * 8, stream));
+    if (launch_search_chain(c->rl, c->cfg.gumbel != 0, stream, c->d, c->mnet, ca, (unsigned)(n_cu / G * G)) != hipSuccess)
+        return fail(MZ_ERR_HIP, "mz_search_run: could not raise the dynamic LDS limit");
+    c->n_expanded += n_sims;
+    return launch_status("mz_search_run");
+}
+
 // mz_search_run, optionally followed by the final action rule (`act->action` non-NULL).  *act_done tells
 // whether the search kernel already ran the rule.
 static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, const double *noise,
@@ -454,7 +619,18 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
         bool by_level = c->rl > 16 || !c->mnet.sched_ok8 ||
                         (size_t)c->mnet.stride * 32 * 4 + (size_t)32 * 16 * 8 > 160 * 1024;
         if (const char *e = getenv("MZ_SEARCH_LEVELS")) by_level = by_level || atoi(e) != 0;
-        if (by_level) return search_by_level(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
+        if (by_level) {
+            // one launch for the whole search where the chained kernel serves the program; MZ_SEARCH_CHAIN = 0: never,
+            // 2: demanded (tests that must not pass on the level-by-level path)
+            bool chained = chain_examine(c) == 1;
+            if (const char *e = getenv("MZ_SEARCH_CHAIN")) {
+                if (atoi(e) == 2 && !chained)
+                    return fail(MZ_ERR_ARG, "mz_search_run: the chained search does not serve this configuration: " + c->chain_why);
+                chained = chained && atoi(e) != 0;
+            }
+            if (chained) return search_chained(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
+            return search_by_level(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
+        }
         // Gumbel trees whose record layout the decision-caching kernel is built for (9 actions: the 3x3 board games)
         // walk down cached decisions and re-decide only the nodes a simulation changed (search_cached.h).
         int ctm = 32;
@@ -1135,8 +1311,17 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     int rc = check_ctx(c, "mz_set_network_mfma");
     if (rc) return rc;
     const MfmaSlot slot{&c->mnet, c->mnet_bufs, &c->mnet_max_k16, &c->mnet_level_job0, &c->mnet_tile_fits};
-    return upload_mfma(c, slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
-                       kidx_h, n_kidx, stride, plane_major, io_h);
+    rc = upload_mfma(c, slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
+                     kidx_h, n_kidx, stride, plane_major, io_h);
+    c->chain_ok = -1; c->chain_G = 0;   // the chained search's work lists belong to the program just replaced
+    if (rc == MZ_OK) {
+        c->mnet_steps_h.assign(steps_h, steps_h + (size_t)n_steps * 12);
+        c->mnet_ctinfo_h.assign(ctinfo_h, ctinfo_h + (size_t)n_jobs * 3);
+        c->mnet_kidx_h.assign(kidx_h, kidx_h + n_kidx);
+    } else {
+        c->mnet_steps_h.clear();
+    }
+    return rc;
 }
 
 extern "C" int mz_set_root_network_mfma(mz_ctx *c, int32_t part, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,

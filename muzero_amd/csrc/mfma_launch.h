@@ -61,4 +61,38 @@ void launch_root_outputs(hipStream_t st, int B, const MfmaNet &pred, const float
 bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, int t_first, int t_end,
                                int leaf, float *acts, const double *noise, int noise_max_calls, int select_next);
 
+// The whole search in one launch, phases chained through tagged data in global memory (search_chain.h).
+#define MZ_CH_TM 16      // trees per tile
+#define MZ_CH_NT 512     // threads per workgroup: waves 0-3 network, 4-7 trees
+#define MZ_CH_SEG 40     // ints per segment descriptor
+#define MZ_CH_KB 20      // weight blocks (16 inputs each) of a column tile held in registers
+#define MZ_CH_PW 36      // floats per row of a wave's output patch (two column tiles + padding)
+
+// Segment descriptor: 0 K (floats, multiple of 16), 1 input offset, 2 output offset of the first column tile,
+// 3 residual offset of the first column tile or -1, 4 activation, 5 first bias entry, 6 column tiles (1..8),
+// 7 dense (every tile multiplies input blocks 0, 1, 2, ...), 8 producing phase of the input (0: the tree waves,
+// l + 1: network level l), 9 producing phase of the residual input, 10 own phase (level + 1), 11 unused,
+// then per column tile: weight byte offset, blocks, first entry in kidx.
+struct ChainArgs {
+    const int32_t *seg;        // [segments][MZ_CH_SEG]
+    const int32_t *blk_range;  // [levels][G + 1]: segments of workgroup m of a cluster at a level
+    float *acts2;              // [rows][stride] granules {float value, uint32 tag}
+    unsigned acts2_bytes;
+    int G, n_clusters, n_tiles;
+    int kk_max;                // widest segment input (floats)
+    int in_lo, in_n;           // the network inputs inside a row: first float, floats (multiple of 16)
+    int out_phase[4];          // producing phase of next state, reward logits, policy logits, value logits
+    int first_leaf, n_sims;
+    const double *noise;
+    int noise_max_calls;
+    long long timeout;         // ticks of the 100 MHz clock that one wait may last
+};
+
+size_t search_chain_lds(const MfmaNet &net, int kk_max, bool gumbel);
+// rl: action lanes of the tree waves (instantiated: see chain_kernels.hip); false: not built for this shape
+bool search_chain_built(int rl);
+hipError_t launch_search_chain(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, const ChainArgs &ca,
+                               unsigned n_blocks);
+
+
 }  // namespace mz

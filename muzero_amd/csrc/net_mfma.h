@@ -16,7 +16,7 @@
 namespace mz {
 
 #ifdef MZ_STAMPS
-__device__ long long mz_dbg_stamps[8 * 1024];   // diagnostic build: cycles per phase, 8 slots per block
+static __device__ long long mz_dbg_stamps[8 * 1024];   // diagnostic build: cycles per phase, 8 slots per block
 #define MZ_KSTAMP(k) { long long n_ = clock64(); if (tid == 0 && blockIdx.x < 1024) mz_dbg_stamps[blockIdx.x * 8 + (k)] = n_ - kst_; kst_ = n_; }
 // the same for kernels that name their slot themselves (slot < 0: none)
 #define MZ_SSTAMP(slot, k) { long long n_ = clock64(); if ((slot) >= 0) mz_dbg_stamps[(slot) * 8 + (k)] = n_ - kst_; kst_ = n_; }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void k_net_epilogue(Dev d, MfmaNet net, int le
 // root; the matrix work in between is k_net_level_rows on each program's own activation rows.
 
 // observations [B][io[11]] into the rows of the representation program (its input tensor starts at io[0])
-__global__ __launch_bounds__(256) void k_root_stage_obs(int B, MfmaNet net, const float *obs, float *acts)
+static __global__ __launch_bounds__(256) void k_root_stage_obs(int B, MfmaNet net, const float *obs, float *acts)
 {
     const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
     if (t >= B) return;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void k_root_hidden(int B, MfmaNet rep, const f
 }
 
 // ... and into the rows of the prediction program (io[8] of that program is 0: no action beside the state)
-__global__ __launch_bounds__(256) void k_root_stage_hidden(int B, MfmaNet pred, const float *hidden, float *acts)
+static __global__ __launch_bounds__(256) void k_root_stage_hidden(int B, MfmaNet pred, const float *hidden, float *acts)
 {
     const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
     if (t >= B) return;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_root_stage_hidden(int B, MfmaNet pred, 
 }
 
 // policy logits and value of every root out of the prediction program's row
-__global__ __launch_bounds__(256) void k_root_outputs(int B, MfmaNet pred, const float *acts, float *out_logits, double *out_value)
+static __global__ __launch_bounds__(256) void k_root_outputs(int B, MfmaNet pred, const float *acts, float *out_logits, double *out_value)
 {
     const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
     if (t >= B) return;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
 
 // The network inputs of every tree's pending selection into its row of `acts` (once per search, after the first
 // selection; later selections are staged by k_leaf_backup_select).
-__global__ __launch_bounds__(256) void k_stage_inputs(Dev d, MfmaNet net, float *acts)
+static __global__ __launch_bounds__(256) void k_stage_inputs(Dev d, MfmaNet net, float *acts)
 {
     const int t = (int)(blockIdx.x * 4 + threadIdx.x / 64), a = threadIdx.x % 64;
     if (t >= d.B) return;

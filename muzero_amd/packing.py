@@ -185,11 +185,13 @@ class PackedMfma:
     dense_macs: int = 0         # what a dense evaluation of the same tiles would compute
 
 
-def _assign_slots(steps, inputs, aliases, keep):
+def _assign_slots(steps, inputs, aliases, keep, reuse=True):
     """Offsets (in floats, multiples of 16) of every tensor in a tree's activation row, reusing the
     space of tensors that are dead: a tensor lives from the level that writes it (inputs: level 0) to
     the last level that reads it (`keep`: to the end).  Everything read or written at a level is
-    disjoint, since the waves of a block work on different jobs of that level at the same time."""
+    disjoint, since the waves of a block work on different jobs of that level at the same time.
+    `reuse` False: every tensor keeps a place of its own (the single-launch search that chains the levels
+    across workgroups has no launch boundary between the last reader of a place and its next writer)."""
     al16 = lambda x: (int(x) + 15) // 16 * 16  # noqa: E731
     base_of = {name: b for name, (b, _, _) in aliases.items()}
     root = lambda n: base_of.get(n, n)  # noqa: E731
@@ -203,7 +205,7 @@ def _assign_slots(steps, inputs, aliases, keep):
         for r in (s.inp, s.skip):
             if r:
                 last_use[root(r)] = max(last_use[root(r)], lv)
-    for n in keep:
+    for n in (list(last_use) if not reuse else keep):
         last_use[root(n)] = 1 << 30
     slots, live, end = {}, [], 0   # live: (offset, units of 16 floats, name)
 
@@ -233,13 +235,14 @@ def _assign_slots(steps, inputs, aliases, keep):
 
 
 def pack_mfma(steps: Sequence, inputs: Dict[str, int], aliases: Dict[str, tuple] = None,
-              keep: Sequence[str] = (), perms: Dict[str, np.ndarray] = None) -> PackedMfma:
+              keep: Sequence[str] = (), perms: Dict[str, np.ndarray] = None, reuse: bool = True) -> PackedMfma:
     """keep: tensors that must survive to the end of the program (what the epilogue reads).
+    reuse: let tensors share a place in the activation row once the earlier one is dead.
     perms: tensor name -> permutation p (position i of the stored tensor holds element p[i] of the program's
     tensor); tensors not named keep their order."""
     aliases = aliases or {}
     perms = perms or {}
-    slots, level_of, end = _assign_slots(steps, inputs, aliases, keep)
+    slots, level_of, end = _assign_slots(steps, inputs, aliases, keep, reuse)
     sizes: Dict[str, int] = {n: int(sz) for n, sz in inputs.items()}
     for name, (base, o, size) in aliases.items():
         sizes[name] = int(size)
@@ -372,9 +375,12 @@ def plane_major_permutation(channels: int, cells: int) -> np.ndarray:
     return np.arange(channels * cells).reshape(channels, cells).T.reshape(-1).copy()
 
 
-def pack_network_mfma(net, plane_major=None):
+def pack_network_mfma(net, plane_major=None, reuse=None):
     """Recurrent program (dynamics + prediction of the parent state) of a lowered network in MFMA
     layout, with the io vector of PackedNetwork.io().
+    reuse: whether dead tensors give their place in the activation row to later ones.  Default: yes for up to 16
+    actions (those searches keep a tile's activations in LDS, where a short row matters), no beyond (those searches
+    run the levels across workgroups in one launch, which needs every tensor in a place of its own).
     Board networks whose channel count is a multiple of 16 store every [channel][cell] feature map of the
     program cell-major, which turns the zero pattern of their lowered convolutions into whole zero blocks
     (`plane_major`, default: on when it applies); stored hidden states keep the reference's order, the kernels
@@ -393,8 +399,10 @@ def pack_network_mfma(net, plane_major=None):
         perms = {s.out: p for s in steps if int(s.W.shape[0]) == H}
         perms['hidden'] = p
         perms['xa'] = np.concatenate([p, H + np.arange(asz)])
+    if reuse is None:
+        reuse = net.A <= 16
     pm = pack_mfma(steps, {'xa': H + asz}, {'hidden': ('xa', 0, H)},
-                   keep=('next_raw', 'reward_logits', 'policy_logits', 'value_logits'), perms=perms)
+                   keep=('next_raw', 'reward_logits', 'policy_logits', 'value_logits'), perms=perms, reuse=reuse)
     pm.plane_major = int(bool(plane_major))
     io = np.asarray([pm.slots['xa'], pm.slots['xa'] + H, pm.slots['next_raw'], pm.slots['reward_logits'],
                      pm.slots['policy_logits'], pm.slots['value_logits'], H, net.A, asz,
