@@ -458,6 +458,7 @@ static int chain_examine(mz_ctx *c)
     auto no = [&](const char *why) { c->chain_why = why; return 0; };
     if (st.empty()) return no("no program");
     if (!search_chain_built(c->rl)) return no("the kernel is not built for this action count");
+    if (net.n_levels > MZ_CH_MAXL) return no("too many network levels");
     const int n_steps = net.n_steps, H = net.io[6], asz = net.io[8];
     const int in_lo = net.io[0], in_n = (H + asz + 15) / 16 * 16;
     if (net.io[1] != in_lo + H) return no("the action does not follow the hidden state in the activation row");
@@ -475,6 +476,7 @@ static int chain_examine(mz_ctx *c)
         if (q[5] >= 0 && q[5] % 16) return no("a residual input does not start on a multiple of 16 floats");
         spans.push_back({q[4], q[4] + q[9] * 16, q[0] + 1});
         kk_max = std::max(kk_max, q[2] * 16);
+        if (q[2] > MZ_CH_MAXB) return no("a layer with more inputs than the kernel's weight ring serves");
         per_level[q[0]] += q[9];
     }
     for (size_t i = 0; i < spans.size(); i++)
@@ -522,32 +524,47 @@ static int chain_prepare(mz_ctx *c, int G)
     (void)H; (void)asz;
     std::vector<int32_t> seg, range;
     for (int l = 0; l < net.n_levels; l++) {
-        std::vector<std::pair<int, int>> tiles;   // (step, column tile)
+        // the level's layers cut into segments of at most 8 column tiles, dealt largest first to the workgroup with
+        // the least work so far (a segment costs a staging of its inputs and one or two column tiles per wave)
+        struct Piece { int s, ct0, n; };
+        std::vector<Piece> pieces;
+        int total = 0;
+        for (int s = 0; s < net.n_steps; s++) if (st[12 * s] == l) total += st[12 * s + 9];
+        const int cap = std::max(1, std::min(8, (total + G - 1) / G));   // so that every workgroup of the cluster gets some
         for (int s = 0; s < net.n_steps; s++)
             if (st[12 * s] == l)
-                for (int ct = 0; ct < st[12 * s + 9]; ct++) tiles.push_back({s, ct});
-        const int total = (int)tiles.size(), share = (total + G - 1) / G;
-        int pos = 0;
+                for (int ct = 0; ct < st[12 * s + 9]; ct += cap) pieces.push_back({s, ct, std::min(cap, st[12 * s + 9] - ct)});
+        std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.n > b.n; });
+        std::vector<std::vector<Piece>> mine(G);
+        std::vector<int> load(G, 0);
+        for (const Piece &pc : pieces) {
+            int m = 0;
+            for (int k = 1; k < G; k++) if (load[k] < load[m]) m = k;
+            mine[m].push_back(pc);
+            load[m] += 4 + pc.n;
+        }
         for (int m = 0; m < G; m++) {
             range.push_back((int)(seg.size() / MZ_CH_SEG));
-            const int end = std::min(total, pos + share);
-            while (pos < end) {
-                const int s = tiles[pos].first, ct0 = tiles[pos].second;
-                int n = 1;
-                while (n < 8 && pos + n < end && tiles[pos + n].first == s) n++;
-                const int32_t *q = &st[12 * s];
-                int32_t d[MZ_CH_SEG] = {q[2] * 16, q[3], q[4] + 16 * ct0, q[5] >= 0 ? q[5] + 16 * ct0 : -1, q[6], q[8] + 16 * ct0,
-                                        n, 1, producer(q[3]), q[5] >= 0 ? producer(q[5]) : 0, l + 1, 0};
-                for (int w = 0; w < n; w++) {
-                    const int32_t *cj = &cti[3 * (q[10] + ct0 + w)];
+            for (const Piece &pc : mine[m]) {
+                const int32_t *q = &st[12 * pc.s];
+                int32_t d[MZ_CH_SEG] = {q[2] * 16, q[3], q[4] + 16 * pc.ct0, q[5] >= 0 ? q[5] + 16 * pc.ct0 : -1, q[6],
+                                        q[8] + 16 * pc.ct0, pc.n, 1, producer(q[3]), q[5] >= 0 ? producer(q[5]) : 0, l + 1, 0};
+                for (int w = 0; w < pc.n; w++) {
+                    const int32_t *cj = &cti[3 * (q[10] + pc.ct0 + w)];
                     d[12 + 3 * w] = cj[0] * 4; d[13 + 3 * w] = cj[2]; d[14 + 3 * w] = cj[1];
                     for (int i = 0; i < cj[2]; i++) if (kidx[cj[1] + i] != i) d[7] = 0;
                 }
                 seg.insert(seg.end(), d, d + MZ_CH_SEG);
-                pos += n;
             }
         }
         range.push_back((int)(seg.size() / MZ_CH_SEG));
+    }
+    {   // a workgroup keeps its segments of all levels in LDS
+        std::vector<int> per_block(G, 0);
+        for (int l = 0; l < net.n_levels; l++)
+            for (int m = 0; m < G; m++) per_block[m] += range[l * (G + 1) + m + 1] - range[l * (G + 1) + m];
+        for (int m = 0; m < G; m++)
+            if (per_block[m] > MZ_CH_MAXSEG) return fail(MZ_ERR_ARG, "mz_search_run: too many network segments per workgroup for the chained search");
     }
     if (c->chain_tab) { (void)hipFree(c->chain_tab); c->chain_tab = nullptr; }
     c->chain_G = 0;
@@ -570,10 +587,11 @@ static int search_chained(mz_ctx *c, int n_sims, const double *noise, int32_t no
     int n_cu = 0;
     HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device));
     const int n_tiles = (c->B + MZ_CH_TM - 1) / MZ_CH_TM;
-    // workgroups per cluster: 8, more when the batch has fewer tiles than clusters (every CU should have work)
+    // workgroups per cluster: 8 (their 32 tree waves serve one tile), more when the batch has fewer tiles than
+    // clusters (every CU should have work)
     int G = 8;
     while (G < 32 && n_cu / (2 * G) >= n_tiles) G *= 2;
-    if (const char *e = getenv("MZ_CHAIN_G")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) G = v; }
+    if (const char *e = getenv("MZ_CHAIN_G")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) G = v; }
     if (n_cu < G) return fail(MZ_ERR_HIP, "mz_search_run: fewer compute units than one cluster of the chained search needs");
     int rc = chain_prepare(c, G);
     if (rc) return rc;
@@ -620,13 +638,15 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
                         (size_t)c->mnet.stride * 32 * 4 + (size_t)32 * 16 * 8 > 160 * 1024;
         if (const char *e = getenv("MZ_SEARCH_LEVELS")) by_level = by_level || atoi(e) != 0;
         if (by_level) {
-            // one launch for the whole search where the chained kernel serves the program; MZ_SEARCH_CHAIN = 0: never,
-            // 2: demanded (tests that must not pass on the level-by-level path)
-            bool chained = chain_examine(c) == 1;
+            // One launch for the whole search (search_chain.h) on request only: MZ_SEARCH_CHAIN = 1 where the kernel
+            // serves the program, 2: demanded (tests that must not pass on the level-by-level path).  Measured slower
+            // than the level-by-level launches on the shapes tried, hence not the default.
+            bool chained = false;
             if (const char *e = getenv("MZ_SEARCH_CHAIN")) {
-                if (atoi(e) == 2 && !chained)
+                const int want = atoi(e);
+                chained = want != 0 && chain_examine(c) == 1;
+                if (want == 2 && !chained)
                     return fail(MZ_ERR_ARG, "mz_search_run: the chained search does not serve this configuration: " + c->chain_why);
-                chained = chained && atoi(e) != 0;
             }
             if (chained) return search_chained(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
             return search_by_level(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);

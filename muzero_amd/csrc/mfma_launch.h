@@ -62,10 +62,14 @@ bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d
                                int leaf, float *acts, const double *noise, int noise_max_calls, int select_next);
 
 // The whole search in one launch, phases chained through tagged data in global memory (search_chain.h).
-#define MZ_CH_TM 16      // trees per tile
+#define MZ_CH_TM 32      // trees per tile
 #define MZ_CH_NT 512     // threads per workgroup: waves 0-3 network, 4-7 trees
 #define MZ_CH_SEG 40     // ints per segment descriptor
-#define MZ_CH_KB 20      // weight blocks (16 inputs each) of a column tile held in registers
+#define MZ_CH_RING 6     // weight blocks (16 inputs each) of a column tile in flight or in use
+#define MZ_CH_MAXB 24    // weight blocks of a column tile: layers of up to 384 inputs
+#define MZ_CH_NF 18      // granule pairs of a segment's inputs that a thread fetches ahead (inputs of up to 288 floats)
+#define MZ_CH_MAXL 16    // network levels
+#define MZ_CH_MAXSEG 16  // segments of one workgroup over all levels (kept in LDS)
 #define MZ_CH_PW 36      // floats per row of a wave's output patch (two column tiles + padding)
 
 // Segment descriptor: 0 K (floats, multiple of 16), 1 input offset, 2 output offset of the first column tile,

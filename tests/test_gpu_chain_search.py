@@ -80,16 +80,16 @@ def _same(a, b):
 
 
 @pytest.mark.parametrize('gumbel', [False, True])
-@pytest.mark.parametrize('G', [4, 8, 32])
+@pytest.mark.parametrize('G', [8, 16, 32])
 def test_chained_search_is_the_level_by_level_search(gumbel, G, monkeypatch):
-    """200 trees (a last tile that is not full) x 60 simulations down long chains, for clusters of 4, 8 and 32
+    """200 trees (a last tile that is not full) x 60 simulations down long chains, for clusters of 8, 16 and 32
     workgroups; the engine is reset and searched twice (tags of the first search must not pass for data)."""
     ref = _search(monkeypatch, WIDE, gumbel, True, 200, 60, chain=False)
     got = _search(monkeypatch, WIDE, gumbel, True, 200, 60, chain=True, G=G, twice=True)
     _same(got, ref)
 
 
-@pytest.mark.parametrize('B', [1, 17, 1024])
+@pytest.mark.parametrize('B', [1, 33, 1024])
 def test_chained_search_batch_sizes(B, monkeypatch):
     """One tree, one tile and a tree, and the benchmark's 1 024 trees (random-init network: shallow trees)."""
     S = 200 if B == 1024 else 50
