@@ -1,6 +1,6 @@
 """Benchmark of the batched MCTS search (BASELINE.json metric: MCTS simulations/sec).
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3h|cfg3s|cfg3t|cfg4|cfg4s|cfg5|cfg5d|cfg5h|cfg5s|cfg5t]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3|cfg3b|cfg3h|cfg3s|cfg3t|cfg4|cfg4s|cfg5|cfg5d|cfg5h|cfg5s|cfg5t]
 
 One process per GPU.  Under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (torchrun) the process is
 one rank; started plainly with --gpus N > 1 it starts the N ranks itself, as fresh child processes, before
@@ -9,9 +9,9 @@ rank's trees with inputs resident in HBM: root inference + root preparation, all
 leaf evaluation (one launch), final action rule.  Weak scaling: every rank searches its own B trees; there is
 no data-path collective inside a search (self-play gathers each move's records on rank 0).
 
-K steps are timed as one block bracketed by barrier + synchronize; when a block is shorter than a second the
-block is repeated (same K, same bracketing) until a second of timed work has accumulated, and the figures are
-taken over all blocks (`timed_blocks`, `timed_region_s` in the output line).
+K steps are timed as one block bracketed by barrier + synchronize; the block is repeated (same K, same bracketing)
+until MIN_TIMED_S seconds of timed work have accumulated, and the figures are taken over all blocks (`timed_blocks`,
+`timed_region_s` in the output line).  MZ_BENCH_MIN_S overrides the duration (profiling passes use short runs).
 
 Default workload = BASELINE.json configs[2], the largest single-GPU configuration: TicTacToe, 16384 trees x
 100 simulations, Gumbel sequential halving, random-init MuZeroResidualNetwork (1 block, 16 channels) evaluated
@@ -73,6 +73,7 @@ WORKLOADS = {
     'cfg4s': ('CartPole 8192 envs x 50 sims PUCT search only, random-init MLP (configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'mlp'),
     'cfg4': ('CartPole self-play 8192 envs/GPU x 50 sims PUCT, fused env step recording every move in a device move log, per-step gather of the records to rank 0 (BASELINE configs[3] per-GPU shard)', False, 2, 50, 1, 0.997, 8192, 'selfplay'),
     'cfg3': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet (1 block, 16 ch), whole search in one launch, leaves evaluated on the matrix cores (BASELINE configs[2])', True, 9, 100, 2, 1, 16384, 'mfma'),
+    'cfg3b': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, through the drop-in MCTS.search_batch call: root noise drawn from np.random per call, roots evaluated and searched on the device, actions / values / policies copied to the host', True, 9, 100, 2, 1, 16384, 'dropin_batch'),
     'cfg3t': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, leaves evaluated by torch ops (comparison)', True, 9, 100, 2, 1, 16384, 'step'),
     'cfg3s': ('TicTacToe 16384 trees x 100 sims Gumbel, random-init ResNet, one leaf-evaluation launch + one backup/selection launch per simulation (comparison)', True, 9, 100, 2, 1, 16384, 'mfma_step'),
     'cfg3h': ('TicTacToe-shaped 16384 trees x 100 sims Gumbel, synthetic hash network (tree kernels only)', True, 9, 100, 2, 1, 16384, 'hash'),
@@ -94,10 +95,11 @@ def algorithmic_bytes(node_visits_total, B, S, A, H, gumbel):
     return levels * (36 + 6 * w + A * (4 + p + 2 * w)) + B * S * (8 * H + p * A + 20 + 3 * w)
 
 
-DEFAULT_STEPS = {'cfg1': 200, 'cfg2': 2000, 'cfg3': 100, 'cfg3h': 200, 'cfg3t': 3, 'cfg3s': 20, 'cfg4': 500, 'cfg4s': 500,
+DEFAULT_STEPS = {'cfg1': 200, 'cfg2': 2000, 'cfg3': 100, 'cfg3b': 50, 'cfg3h': 200, 'cfg3t': 3, 'cfg3s': 20, 'cfg4': 500, 'cfg4s': 500,
                  'cfg5': 50, 'cfg5d': 50, 'cfg5s': 20, 'cfg5h': 200, 'cfg5t': 5}
-MIN_TIMED_S = 1.0     # repeat the block of K steps until this much timed work has accumulated
-MAX_BLOCKS = 200
+MIN_TIMED_S = 8.0     # repeat the block of K steps until this much timed work has accumulated (the GPU leg of the
+                      # default command is then as long as its CPU-baseline leg)
+MAX_BLOCKS = 2000
 
 
 def parse_args(argv=None):
@@ -190,6 +192,17 @@ def main():
         np.random.seed(0)
         searcher.search(net, obs0, np.ones(9), enc, 0, 1.0)
         eng = searcher.last_engine
+    elif leaf == 'dropin_batch':
+        sys.path.insert(0, os.path.join(REPO, 'muzero_amd'))
+        from mcts.mcts import MCTS  # the drop-in package, imported under the reference's name
+        net = MuZeroNetwork(tictactoe_net_config(), seed=0)
+        H = net.H
+        searcher = MCTS(cfg)
+        obs = torch.as_tensor(tictactoe_roots(rng, B).reshape(B, 27), device=dev)
+        legal_h, to_play_h = np.ones((B, A)), np.zeros(B, np.int32)
+        np.random.seed(0)
+        searcher.search_batch(net, obs, legal_h, to_play_h, 1.0, tree_id0=tree_id0)
+        eng = searcher.last_engine
     elif leaf == 'selfplay':
         from muzero_amd.self_play import BatchedSelfPlay
         cfg.max_moves = 500
@@ -268,6 +281,13 @@ def main():
             if i is not None:
                 ev[i][0].record()
             out = searcher.search(net, obs0, np.ones(9), enc, 0, 1.0)
+            if i is not None:
+                ev[i][1].record()
+            return out
+        if leaf == 'dropin_batch':
+            if i is not None:
+                ev[i][0].record()
+            out = searcher.search_batch(net, obs, legal_h, to_play_h, 1.0, tree_id0=tree_id0)
             if i is not None:
                 ev[i][1].record()
             return out
@@ -351,7 +371,7 @@ def main():
         elapsed += block
         blocks += 1
         kern_ms_all += [a.elapsed_time(b) for a, b in ev]
-        if elapsed >= MIN_TIMED_S or blocks >= MAX_BLOCKS:
+        if elapsed >= float(os.environ.get('MZ_BENCH_MIN_S', MIN_TIMED_S)) or blocks >= MAX_BLOCKS:
             break
     n_steps = blocks * args.steps
 
@@ -363,10 +383,20 @@ def main():
     sims = world * B * S * n_steps
     nv_all = mzdist.sum_over_ranks(node_visits, rdev)
 
-    traffic = None
-    try:  # HBM bytes per launch from the PMC counters, measured offline with rocprofv3 (profiles/hbm_traffic.json)
+    # HBM bytes per launch from the PMC counters, measured offline with rocprofv3 (profiles/hbm_traffic.json).  An entry
+    # belongs to the kernel sources it was measured on: with other sources the line carries no traffic figure.
+    traffic, traffic_note = None, None
+    try:
+        from muzero_amd.build import source_fingerprint
         with open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')) as f:
-            traffic = json.load(f).get(args.workload, {}).get('traffic_bytes_per_launch')
+            entry = json.load(f).get(args.workload)
+        if entry is not None and os.environ.get('MZ_BENCH_TREES') is None:
+            if entry.get('kernel_sources') == source_fingerprint():
+                traffic = entry.get('traffic_bytes_per_launch')
+            else:
+                traffic_note = ('profiles/hbm_traffic.json was measured on other kernel sources (%s, now %s): run '
+                                'scripts/profile_round.sh + scripts/pmc_summary.py again'
+                                % (entry.get('kernel_sources'), source_fingerprint()))
     except OSError:
         pass
     out = {
@@ -383,10 +413,10 @@ def main():
         'recording': ({'where': 'device move log, written by k_act_env', 'games_recorded_rank0': games_recorded,
                        'moves_recorded_rank0': B * n_steps} if leaf == 'selfplay' else None),
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
-                                'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation' if A > 16 else 'k_search_mfma'), 'mfma_step': ('k_stage_inputs + k_net_level_rows x levels + k_net_epilogue + k_backup_select, per simulation' if A > 16 else 'k_net_step+k_backup_select'), 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the level kernels, k_search_mfma, host copies)',
+                                'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation' if A > 16 else 'k_search_mfma'), 'mfma_step': ('k_stage_inputs + k_net_level_rows x levels + k_net_epilogue + k_backup_select, per simulation' if A > 16 else 'k_net_step+k_backup_select'), 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the level kernels, k_search_mfma, host copies)', 'dropin_batch': 'MCTS.search_batch (root noise from np.random, root inference on the level kernels, k_search_gcache, host copies)',
                                 'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': traffic, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
+                     'traffic': traffic, 'traffic_note': traffic_note, 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg,
                      'limiter': LIMITER['mfma_levels'] if (leaf in ('mfma', 'mfma_step') and A > 16) else LIMITER.get(leaf, LIMITER['tree'])},
     }
 
@@ -459,7 +489,7 @@ def run_stub(args, rank, world):
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(cfg, net, leaf, A, S, H, B, gumbel, budget_s=10.0):
+def cpu_baseline(cfg, net, leaf, A, S, H, B, gumbel, budget_s=8.0):
     """The CPU checker (oracle/, a C port of the reference's search) timed on this box's host cores on a
     bounded sample of the SAME workload - same rule, simulations, action count and leaf evaluator (the lowered
     network executed as a dense program; the hash network for the hash workloads): batches of trees, one tree
@@ -470,7 +500,7 @@ def cpu_baseline(cfg, net, leaf, A, S, H, B, gumbel, budget_s=10.0):
     threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or (os.cpu_count() or 1)
     rng = np.random.default_rng(1)
     kind = 'hash network'
-    if leaf in ('mlp', 'selfplay', 'mfma', 'step', 'mfma_step', 'step5', 'dropin'):
+    if leaf in ('mlp', 'selfplay', 'mfma', 'step', 'mfma_step', 'step5', 'dropin', 'dropin_batch'):
         cpu_net = net.to('cpu') if hasattr(net, 'to') else net
         packed = pack_network(cpu_net)
         # a batch that takes on the order of a second: ~2 ns per multiply-accumulate and thread

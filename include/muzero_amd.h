@@ -379,6 +379,15 @@ int mz_scalar_to_support(const float *x, int64_t n, int32_t support_limit, float
 /* Sequential-halving schedule, mcts/action_selection.py:160-175 (host, pure integer). out_h i32[S]. */
 int mz_considered_visits(int32_t max_considered_actions, int32_t simulations, int32_t *out_h);
 
+/* Root noise of B consecutive PUCT searches out of NumPy's legacy generator (host, no GPU): per search one
+ * np.random.dirichlet([alpha] * A) row (mcts/mcts.py:27) and - with_uniform != 0 - the np.random.random_sample() that
+ * np.random.choice draws for the final action (mcts/action_selection.py:69), in that order, search after search.
+ * mt_key u32[624] and *mt_pos are the MT19937 state of np.random.get_state(), advanced in place to where B such searches
+ * leave the stream.  alpha must lie in (0, 1) (the rejection sampler of NumPy's legacy standard_gamma for shapes below
+ * one is restated; other shapes: MZ_ERR_ARG, draw with NumPy).  out_dirichlet f64[B][A], out_u f64[B] or NULL. */
+int mz_legacy_root_noise(uint32_t *mt_key, int32_t *mt_pos, double alpha, int32_t n_actions, int32_t B,
+                         int32_t with_uniform, double *out_dirichlet, double *out_u);
+
 /* Library/ABI version. */
 int mz_version(void);
 

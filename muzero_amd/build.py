@@ -16,6 +16,19 @@ HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.joi
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17']
 
 
+def source_fingerprint() -> str:
+    """sha256 (16 hex digits) over the kernel sources - every .hip and .h under csrc/ and the public header - in name
+    order.  Measurements that belong to one state of the kernels (HBM traffic from the counter passes) carry it, so
+    that a reader can tell whether they still describe the code at hand."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(f).encode())
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
         return True

@@ -105,6 +105,81 @@ extern "C" int mz_considered_visits(int32_t m, int32_t S, int32_t *out_h)
     return MZ_OK;
 }
 
+// NumPy's legacy generator (numpy/random/src/mt19937/mt19937.c, src/legacy/legacy-distributions.c, 2.2.6), restated
+// for the one sequence the drop-in draws per tree: a Dirichlet row with one shape below 1, then optionally a uniform.
+namespace {
+struct LegacyMT {
+    uint32_t *key;
+    int pos;
+    void refill()
+    {
+        const int N = 624, M = 397;
+        const uint32_t MATRIX_A = 0x9908b0dfu, UPPER = 0x80000000u, LOWER = 0x7fffffffu;
+        int kk;
+        uint32_t y;
+        for (kk = 0; kk < N - M; kk++) {
+            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
+            key[kk] = key[kk + M] ^ (y >> 1) ^ (-(y & 1) & MATRIX_A);
+        }
+        for (; kk < N - 1; kk++) {
+            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
+            key[kk] = key[kk + (M - N)] ^ (y >> 1) ^ (-(y & 1) & MATRIX_A);
+        }
+        y = (key[N - 1] & UPPER) | (key[0] & LOWER);
+        key[N - 1] = key[M - 1] ^ (y >> 1) ^ (-(y & 1) & MATRIX_A);
+        pos = 0;
+    }
+    uint32_t next32()
+    {
+        if (pos == 624) refill();
+        uint32_t y = key[pos++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    double next_double()
+    {
+        const int32_t a = (int32_t)(next32() >> 5), b = (int32_t)(next32() >> 6);
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    double standard_exponential() { return -std::log(1.0 - next_double()); }
+    double standard_gamma_below_one(double shape)
+    {
+        for (;;) {
+            const double U = next_double(), V = standard_exponential();
+            if (U <= 1.0 - shape) {
+                const double X = std::pow(U, 1. / shape);
+                if (X <= V) return X;
+            } else {
+                const double Y = -std::log((1 - U) / shape);
+                const double X = std::pow(1.0 - shape + shape * Y, 1. / shape);
+                if (X <= (V + Y)) return X;
+            }
+        }
+    }
+};
+}  // namespace
+
+extern "C" int mz_legacy_root_noise(uint32_t *mt_key, int32_t *mt_pos, double alpha, int32_t A, int32_t B,
+                                    int32_t with_uniform, double *out_dirichlet, double *out_u)
+{
+    if (!mt_key || !mt_pos || !out_dirichlet || A < 1 || B < 0 || *mt_pos < 0 || *mt_pos > 624 || (with_uniform && !out_u))
+        return fail(MZ_ERR_ARG, "mz_legacy_root_noise: bad argument");
+    if (!(alpha > 0.0 && alpha < 1.0)) return fail(MZ_ERR_ARG, "mz_legacy_root_noise: alpha must lie in (0, 1)");
+    LegacyMT mt{mt_key, *mt_pos};
+    for (int b = 0; b < B; b++) {
+        double *row = out_dirichlet + (size_t)b * A, acc = 0.0;
+        for (int j = 0; j < A; j++) { row[j] = mt.standard_gamma_below_one(alpha); acc = acc + row[j]; }
+        const double invacc = 1 / acc;
+        for (int j = 0; j < A; j++) row[j] = row[j] * invacc;
+        if (with_uniform) out_u[b] = mt.next_double();
+    }
+    *mt_pos = mt.pos;
+    return MZ_OK;
+}
+
 extern "C" const char *mz_last_error(void) { return g_err.c_str(); }
 extern "C" int mz_version(void) { return 1; }
 

@@ -117,10 +117,14 @@ class StepGather:
         Returns on `dst` a dict name -> tensor over all ranks' trees in rank order, None on the other ranks."""
         if not self.active:
             return {name: record[name] for name, _ in RECORD_FIELDS if name in record}
+        # Copies into the send buffer may be asynchronous only when the buffer lives on the records' device: the
+        # collective is then ordered behind them on the current stream.  A host buffer (gloo) filled from device
+        # records by a non-blocking copy could still hold the previous move's bytes when gloo reads it.
         for name, dtype in RECORD_FIELDS:
             x = record.get(name)
             if x is not None:
-                self._field(self.send, name, dtype)[:self.b].copy_(x.reshape(self.b, self.widths[name]), non_blocking=True)
+                dst_view = self._field(self.send, name, dtype)[:self.b]
+                dst_view.copy_(x.reshape(self.b, self.widths[name]), non_blocking=x.device == dst_view.device)
         dist.gather(self.send, self.recv, dst=self.dst)
         if self.rank != self.dst:
             return None

@@ -57,7 +57,7 @@ ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_set_seed', 'mz_check', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
            'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_set_root_network_mfma', 'mz_initial_inference_mfma', 'mz_expand_backup_net', 'mz_expand_backup_net_static', 'mz_act_env_step', 'mz_act_env_step_log', 'mz_log_count_games', 'mz_log_list_games', 'mz_tree_export',
-           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_make_targets', 'mz_scalar_to_support',
+           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_legacy_root_noise', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
 
@@ -103,6 +103,7 @@ def lib():
         L.mz_tree_export.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp]
         L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
         L.mz_stats.argtypes = [vp, vp, vp, vp]
+        L.mz_legacy_root_noise.argtypes = [vp, vp, C.c_double, i32, i32, i32, vp, vp]
         L.mz_node_qtransform.argtypes = [vp, i32, i32, i32, vp, vp]
         L.mz_node_select.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         L.mz_considered_visits.argtypes = [i32, i32, vp]
@@ -124,6 +125,33 @@ def considered_visits(max_considered_actions: int, simulations: int) -> tuple:
     _check(lib().mz_considered_visits(int(max_considered_actions), int(simulations),
                                       out.ctypes.data_as(C.c_void_p)))
     return tuple(int(x) for x in out)
+
+
+def legacy_root_noise(alpha: float, n_actions: int, B: int, with_uniform: bool):
+    """Root noise of B consecutive PUCT searches from the GLOBAL NumPy stream, in one native call: per search one
+    `np.random.dirichlet([alpha] * A)` row (mcts/mcts.py:27) and, with_uniform, the `random_sample()` behind the final
+    `np.random.choice` (mcts/action_selection.py:69), in that order.  The stream is left where B such searches would
+    leave it.  Falls back to drawing with NumPy row by row where the native generator does not apply (alpha >= 1, a
+    global generator that is not MT19937, a pending cached Gaussian is kept either way).
+    Returns (dirichlet f64[B, A], u f64[B] or None)."""
+    A = int(n_actions)
+    state = np.random.get_state()
+    if not (0.0 < alpha < 1.0) or state[0] != 'MT19937':
+        di, u = np.empty((B, A)), (np.empty(B) if with_uniform else None)
+        for b in range(B):
+            di[b] = np.random.dirichlet([alpha] * A)
+            if with_uniform:
+                u[b] = np.random.random_sample()
+        return di, u
+    key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(state[2]))
+    di = np.empty((B, A), np.float64)
+    u = np.empty(B, np.float64) if with_uniform else None
+    _check(lib().mz_legacy_root_noise(key.ctypes.data_as(C.c_void_p), C.byref(pos), float(alpha), A, int(B),
+                                      1 if with_uniform else 0, di.ctypes.data_as(C.c_void_p),
+                                      u.ctypes.data_as(C.c_void_p) if with_uniform else None), 'mz_legacy_root_noise')
+    np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
+    return di, u
 
 
 def c_table_numpy(config) -> np.ndarray:

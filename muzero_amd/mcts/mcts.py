@@ -34,6 +34,18 @@ def _to_numpy(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
 
+def network_device(network) -> torch.device:
+    """Where a network object wants its inputs: its `device` attribute, else the device of its first parameter, else
+    the host (plain Python objects such as the synthetic hash network)."""
+    d = getattr(network, 'device', None)
+    if d is not None:
+        return torch.device(d)
+    if isinstance(network, torch.nn.Module):
+        for p in network.parameters():
+            return p.device
+    return torch.device('cpu')
+
+
 class MCTS:
 
     def __init__(self, config) -> None:
@@ -126,7 +138,9 @@ class MCTS:
                 stream_noise, seed=0, tree_id0=0):
         cfg = self.config
         A, S = int(cfg.n_actions), int(cfg.simulations)
-        obs = torch.as_tensor(np.asarray(observations), dtype=torch.float32)
+        # (observations may already be a tensor on the device: batched callers build them there)
+        obs = (observations.to(torch.float32) if isinstance(observations, torch.Tensor)
+               else torch.as_tensor(np.asarray(observations), dtype=torch.float32))
         B = obs.shape[0]
         legal = np.asarray(legal_actions, dtype=np.float64).reshape(B, A)
         gumbel = bool(cfg.gumbel)
@@ -139,7 +153,7 @@ class MCTS:
             H, logits, hidden, value = int(network.H), None, None, None
         else:
             with torch.no_grad():
-                logits, hidden, value = network.initial_inference(obs)
+                logits, hidden, value = network.initial_inference(obs.to(network_device(network)))
             hidden_shape = tuple(hidden.shape[1:])
             H = int(np.prod(hidden_shape))
         eng = self._engine_for(H, B, noise_mode, seed)
@@ -153,18 +167,17 @@ class MCTS:
             eng._plan_of = (id(network), id(plan))
         if plan is not None and plan[0] == 'mfma':
             logits, hidden, value = eng.initial_inference_mfma(obs.reshape(B, -1))
+        # Root noise from the global NumPy stream in the order B consecutive reference searches consume it (their
+        # tie-break uniforms aside), drawn in ONE call per batch: a Python-level draw per tree costs more than the
+        # search once batches reach thousands of trees.
         g = dirichlet = u_pre = None
         if gumbel:
-            g = np.stack([np.random.gumbel(size=A) for _ in range(B)])
+            g = np.random.gumbel(size=(B, A))     # row b = the b-th search's np.random.gumbel(size=A) (mcts/mcts.py:211)
         elif stream_noise:
-            dirichlet = np.stack([np.random.dirichlet([cfg.dirichlet_alpha] * A) for _ in range(B)])
+            dirichlet, _ = _engine.legacy_root_noise(float(cfg.dirichlet_alpha), A, B, with_uniform=False)
         else:
-            # per tree: Dirichlet row, then the uniform of the final np.random.choice - the order in
-            # which B consecutive reference searches (tie-break uniforms aside) consume the stream
-            dirichlet, u_pre = np.empty((B, A)), np.empty(B)
-            for b in range(B):
-                dirichlet[b] = np.random.dirichlet([cfg.dirichlet_alpha] * A)
-                u_pre[b] = np.random.random_sample()
+            # per tree: Dirichlet row, then the uniform of the final np.random.choice
+            dirichlet, u_pre = _engine.legacy_root_noise(float(cfg.dirichlet_alpha), A, B, with_uniform=True)
         frac = 0.0 if gumbel else cfg.exploration_frac
         tp = np.asarray(to_play, dtype=np.int32).reshape(B)
         if plan is not None and plan[0] == 'fused':
@@ -205,7 +218,7 @@ class MCTS:
                 np.random.set_state(rng_state)
                 for n in calls.cpu().numpy():  # advance past the rows the search used
                     np.random.uniform(size=(int(n), A))
-            u = u_pre if u_pre is not None else np.array([np.random.random_sample() for _ in range(B)])
+            u = u_pre if u_pre is not None else np.random.random_sample(B)
         action, root_value, probs, _ = eng.to_act(float(temperature), u)
         self.last_engine = eng
         self._last_meta = (legal, g)

@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 from . import noise as _noise
-from .mcts.mcts import MCTS
+from .mcts.mcts import MCTS, network_device
+from .targets import TrajectoryStore
 
 
 class BatchedReanalyser:
@@ -35,22 +36,24 @@ class BatchedReanalyser:
         (`save_reanalysed_stats`) and returns them; positions are batched in game order, and position
         k of the batch uses tie-break noise key `tree_id0 + k`."""
         cfg = self.config
-        stack = lambda h, t: h.stack_n_observations(t, cfg.n_stacked_observations, cfg.n_actions, cfg.stack_action)  # noqa: E731
-        obs, to_play, owner = [], [], []
-        for g, h in enumerate(histories):
-            for t in range(len(h)):
-                obs.append(np.asarray(stack(h, t), dtype=np.float64))
-                to_play.append(h.to_plays[t])
-                owner.append(g)
-        if not obs:
+        lengths = np.array([len(h) for h in histories], dtype=np.int64)
+        B = int(lengths.sum())
+        if B == 0:
             return []
-        obs = np.stack(obs)
-        B = len(obs)
+        to_play = np.concatenate([np.asarray(h.to_plays[:n], dtype=np.int64) for h, n in zip(histories, lengths) if n])
+        # stacked observations of every position (games/game.py:120-160) by the kernel that builds training batches:
+        # one launch over all positions instead of a Python call per position
+        played = [h for h, n in zip(histories, lengths) if n]
+        store = TrajectoryStore(played, cfg.n_actions)
+        gi = np.repeat(np.arange(len(played)), lengths[lengths > 0])
+        ts = np.concatenate([np.arange(n) for n in lengths if n])
+        obs = store.make_targets(gi, ts, np.full((B, 1), -1), 0, float(getattr(cfg, 'gamma', 1.0)), 0,
+                                 int(cfg.n_stacked_observations), bool(cfg.stack_action))[0]
         legal = np.repeat(np.asarray(self.game.legal_actions(), dtype=np.float64)[None], B, axis=0)
         values = None
         if not getattr(cfg, 'mcts_target_value', True):
             with torch.no_grad():
-                values = self.target_network.initial_inference(torch.as_tensor(obs, dtype=torch.float32))[2]
+                values = self.target_network.initial_inference(obs.to(network_device(self.target_network)))[2]
             values = np.asarray(values.detach().cpu().numpy(), dtype=np.float64).reshape(B)
         _, root_values, probs = self.mcts.search_batch(self.target_network, obs, legal, np.asarray(to_play), 0,
                                                        action_encoder=self.game.action_encoder,

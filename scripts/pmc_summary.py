@@ -2,6 +2,8 @@
 under profiles/: per-workload kernel statistics (csv copied as is) and HBM bytes per launch of the
 dominant kernel.  Usage: python scripts/pmc_summary.py <tag> <round-name>"""
 import csv, glob, json, os, shutil, sys
+sys.path.insert(0, '.')
+from muzero_amd.build import source_fingerprint
 
 tag, rnd = sys.argv[1], sys.argv[2]
 DOMINANT = {'cfg3': 'k_search_gcache', 'cfg2': 'k_search_reg', 'cfg4s': 'k_search_reg', 'cfg3h': 'k_search_hash',
@@ -48,7 +50,15 @@ for w, kern in DOMINANT.items():
     if len(vals) == 2:
         f, wr = vals['FETCH_SIZE'][0], vals['WRITE_SIZE'][0]
         traffic[w] = {'kernel': vals['FETCH_SIZE'][2], 'fetch_size_kb': f, 'write_size_kb': wr,
-                      'traffic_bytes_per_launch': (2 * f + wr) * 1024, 'method': NOTE}
+                      'traffic_bytes_per_launch': (2 * f + wr) * 1024, 'method': NOTE,
+                      'kernel_sources': source_fingerprint()}
 json.dump(raw, open(f'profiles/{rnd}_pmc_hbm_traffic_raw.json', 'w'), indent=1)
+# workloads not profiled in this run keep their earlier entries (with the fingerprint of the sources they were measured on)
+try:
+    old = json.load(open('profiles/hbm_traffic.json'))
+except OSError:
+    old = {}
+old.update(traffic)
+traffic = old
 json.dump(traffic, open('profiles/hbm_traffic.json', 'w'), indent=1)
 print(json.dumps(traffic, indent=1))

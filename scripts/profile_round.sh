@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_default -o r --output-format csv -- \
     python3 $root/bench.py > $out/${tag}_stats_default.json 2> $out/${tag}_stats_default.err
 echo "profiled the default command"
+export MZ_BENCH_MIN_S=0.5   # the other passes time one short block each (set here: nothing may stand between rocprofv3's "--" and the program)
 for w in ${WORKLOADS:-cfg3 cfg2 cfg4s cfg3h cfg5}; do
     timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_$w -o r --output-format csv -- \
         python3 $root/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_stats_$w.json 2> $out/${tag}_stats_$w.err

@@ -79,3 +79,24 @@ def replay_on_checker(cfg, tree, H, legal, to_play, seed=0, tree_id=0, gumbel_no
     o.init(tree['children_prior_logits'][0], tree['node_raw_values'][0], tree['hidden_states'][0], to_play, legal, gumbel_noise)
     o.search(o.table_net(rec_logits, rec_value, rec_reward, rec_hidden), o.counter_noise(seed, tree_id))
     return o
+
+
+def hidden_conditioned_error(net, parent_hidden, actions, stored_next_hidden):
+    """Largest error of stored next hidden states, measured where it is well conditioned: the reference scales every
+    group (plane) of the dynamics' raw output as (x - min) / (max - min + 1e-5) (utils/network_utils.py:132-158), which
+    divides last-bit differences of the raw output by the plane's range - unbounded for a nearly flat plane.  Multiplied
+    back by that range, the difference of two float32 evaluators is again a few ulps of the raw values.
+    net: lowered network on the CPU (muzero_amd.network); parent_hidden f32[n, H]; actions int[n]; stored f32[n, H].
+    Returns max over elements of |stored - reference| * (range of the element's group + 1e-5)."""
+    import torch
+    h = torch.as_tensor(np.ascontiguousarray(parent_hidden, np.float32))
+    a = torch.as_tensor(np.asarray(actions, np.int64))
+    with torch.no_grad():
+        raw = net.dyn.run({'xa': torch.cat([h, net.encode_actions(a)], dim=1)})['next_raw'].numpy()
+    n, H = raw.shape
+    groups = int(net.norm_groups)
+    r = raw.reshape(n, groups, H // groups)
+    mn, mx = r.min(axis=2, keepdims=True), r.max(axis=2, keepdims=True)
+    ref = (r - mn) / (mx - mn + np.float32(1e-5))
+    got = np.asarray(stored_next_hidden, np.float32).reshape(n, groups, H // groups)
+    return float((np.abs(got - ref) * (mx - mn + 1e-5)).max())

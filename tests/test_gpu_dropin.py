@@ -243,3 +243,32 @@ def test_single_search_with_stream_noise_same_on_every_path(mcts_pkg, monkeypatc
         np.testing.assert_allclose(out[0][2], out[1][2], atol=1e-6)
         agree += out[0][0] == out[1][0] and out[0][3] == out[1][3]   # same action, stream left at the same place
     assert agree >= 5
+
+
+@pytest.mark.parametrize('gumbel', [True, False])
+def test_search_batch_leaves_the_numpy_stream_where_consecutive_searches_would(mcts_pkg, gumbel):
+    """search_batch draws the root noise of all its trees in one call; the global stream must end where B consecutive
+    reference searches (mcts/mcts.py:211 / :27, mcts/action_selection.py:69; tie-break uniforms aside, which the
+    batched search takes from its counter function) leave it, and tree b must have been given the b-th draw."""
+    m = mcts_pkg[0]
+    A, S, B, H = 9, 12, 37, 8
+    cfg = make_config(gumbel, A, S, 2, 1.0)
+    hp = hashnet.HashNetParams(A, H, 4, 1, 1)
+    net = hashnet.HashNetwork(hp)
+    obs = np.stack([hashnet.observation_of(1000 + b) for b in range(B)])
+    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    np.random.seed(99)
+    if gumbel:
+        want_noise = np.stack([np.random.gumbel(size=A) for _ in range(B)])
+    else:
+        for _ in range(B):
+            np.random.dirichlet([cfg.dirichlet_alpha] * A)
+            np.random.random_sample()
+    want_next = np.random.random_sample(4)
+    np.random.seed(99)
+    search = m.MCTS(cfg)
+    search.search_batch(net, obs, legal, tp, 1.0, action_encoder=lambda a: np.eye(A)[a])
+    np.testing.assert_array_equal(np.random.random_sample(4), want_next)
+    if gumbel:
+        for b in (0, B // 2, B - 1):
+            np.testing.assert_array_equal(search.last_tree(b).gumbel_noise, want_noise[b])

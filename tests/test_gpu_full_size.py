@@ -18,7 +18,7 @@ import pytest
 import torch
 
 import bench   # the workloads' network shapes, as benchmarked
-from helpers import make_config, assert_tree_equal, replay_on_checker
+from helpers import make_config, assert_tree_equal, replay_on_checker, hidden_conditioned_error
 from muzero_amd.network import MuZeroNetwork
 from muzero_amd.packing import pack_network, pack_network_mfma
 
@@ -27,11 +27,14 @@ pytestmark = pytest.mark.gpu
 TICTACTOE, CARTPOLE, ATARI_LIKE = bench.tictactoe_net_config(), bench.cartpole_net_config(), bench.atari_like_net_config()
 
 
-def _explain(cfg, packed, trees, idx, legal, tp, seed, tid0, g, tol, hidden_tol):
+def _explain(cfg, packed, trees, idx, legal, tp, seed, tid0, g, tol, hidden_tol, net):
     """Trees `idx` (exports in `trees`): the checker rebuilds each from its own stored leaf outputs, and those outputs are
-    within tolerance of the checker's dense executor on the same (parent state, action)."""
+    within tolerance of the checker's dense executor on the same (parent state, action).  Next hidden states: always
+    at the conditioned bound (difference times the range of the scaled plane <= 5e-6), and directly at `hidden_tol`
+    where the planes are wide enough for that (None: boards, whose 9-cell planes can be nearly flat)."""
     from oracle import oracle as orc
     S = cfg.simulations
+    worst_h = 0.0
     for b in idx:
         t = trees[b]
         o = replay_on_checker(cfg, t, packed.H, legal[b], int(tp[b]), seed, tid0 + b, None if g is None else g[b])
@@ -42,10 +45,14 @@ def _explain(cfg, packed, trees, idx, legal, tp, seed, tid0, g, tol, hidden_tol)
         assert np.abs(val - t['node_raw_values'][1:]).max() <= tol and np.abs(rew - t['children_rewards'][par, act]).max() <= tol, b
         if hidden_tol is not None:
             assert np.abs(nh - t['hidden_states'][1:].reshape(S, -1)).max() <= hidden_tol, b
+        err = hidden_conditioned_error(net, t['hidden_states'][par].reshape(S, -1), act, t['hidden_states'][1:].reshape(S, -1))
+        worst_h = max(worst_h, err)
+        assert err <= 5e-6, (b, err)
+    print(f'   next hidden states of {len(idx)} trees: largest difference x plane range {worst_h:.2e}')
 
 
 def _full_size(name, net_cfg, gumbel, A, S, players, gamma, B, obs, search, with_mfma, min_share, tol, hidden_tol,
-               monkeypatch, root_tol=None):
+               monkeypatch, root_tol=None, root_median=None, root_share_1e5=None):
     from muzero_amd.engine import SearchEngine
     from oracle import oracle as orc
     seed, tid0 = 6, 3000
@@ -92,6 +99,12 @@ def _full_size(name, net_cfg, gumbel, A, S, players, gamma, B, obs, search, with
     print(f'{name}: {B} trees x {S} simulations; action and visit total identical {same.mean():.4f}, '
           f'root value within {root_tol:g} {close.mean():.4f}, mean leaf depth {nv.mean() / S - 1:.2f}')
     assert same.mean() >= min_share and (close | ~same).mean() >= 0.99
+    dv = np.abs(root_value - ref.root_value)
+    print(f'   root values: median difference {np.median(dv):.2e}, within 1e-5 on {(dv < 1e-5).mean():.4f} of the trees')
+    if root_median is not None:
+        assert np.median(dv) <= root_median
+    if root_share_1e5 is not None:
+        assert (dv < 1e-5).mean() >= root_share_1e5
     assert abs(int(nv.sum()) - int(ref.node_visits.sum())) <= 0.01 * ref.node_visits.sum()
     legal_pick = legal[every, action] == 1
     assert legal_pick.all() and np.isfinite(root_value).all()
@@ -104,7 +117,7 @@ def _full_size(name, net_cfg, gumbel, A, S, players, gamma, B, obs, search, with
     visits = np.stack([trees[b]['children_visits'][0] for b in sample])
     agree = (visits == ref.root_visits[sample]).all(axis=1)
     assert (agree | ~same[sample]).all()                                # the cheap signature is not hiding differences
-    _explain(cfg, packed, trees, sorted(trees), legal, tp, seed, tid0, g, tol, hidden_tol)
+    _explain(cfg, packed, trees, sorted(trees), legal, tp, seed, tid0, g, tol, hidden_tol, net)
     # the sampled roots again, as a small batch at other batch positions: the very same trees
     rows = np.asarray(sample)
     if gumbel:      # no per-tree random stream: any tree id will do
@@ -134,24 +147,25 @@ def test_tictactoe_gumbel_16384_trees(monkeypatch):
     boards = rng.integers(0, 3, size=(B, 9)) - 1
     obs = np.stack([(boards == -1), (boards == 1), np.ones_like(boards) * -1], axis=1).astype(np.float32).reshape(B, 27)
     # The per-plane min-max scaling of a hidden state (9 cells) amplifies last-bit differences of a nearly flat plane, and
-    # these searches run 15 levels deep, so two float32 evaluators drift apart along a chain: no bound on hidden states,
-    # and root values (means over 100 leaf values) are compared at 5e-3 (median difference 3e-5).  What is exact is
-    # checked exactly: every leaf output within 1e-5 of the checker's on the SAME stored inputs, and the trees rebuilt
-    # bit for bit from the stored outputs.
-    _full_size('tictactoe', TICTACTOE, True, 9, 100, 2, 1, B, obs, lambda e: e.search_mfma(), True, 0.90, 1e-5, None,
-               monkeypatch, root_tol=5e-3)
+    # these searches run 15 levels deep, so two float32 evaluators drift apart along a chain: hidden states are bounded
+    # where they are well conditioned (difference x plane range), the share of identical trees at what was measured
+    # (0.9796) less 0.01, and root values (means over 100 leaf values) by their median (measured 3e-5) and by the
+    # share within 1e-5; the outliers at 5e-3.  What is exact is checked exactly: every leaf output within 1e-5 of the
+    # checker's on the SAME stored inputs, and the trees rebuilt bit for bit from the stored outputs.
+    _full_size('tictactoe', TICTACTOE, True, 9, 100, 2, 1, B, obs, lambda e: e.search_mfma(), True, 0.97, 1e-5, None,
+               monkeypatch, root_tol=5e-3, root_median=1e-4, root_share_1e5=0.25)
 
 
 def test_cartpole_puct_8192_trees(monkeypatch):
     B = 8192
     obs = np.random.default_rng(3).uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32)
-    _full_size('cartpole', CARTPOLE, False, 2, 50, 1, 0.997, B, obs, lambda e: e.search_net(), False, 0.98, 1e-5, 1e-4,
-               monkeypatch)
+    _full_size('cartpole', CARTPOLE, False, 2, 50, 1, 0.997, B, obs, lambda e: e.search_net(), False, 0.99, 1e-5, 1e-4,
+               monkeypatch, root_median=1e-6, root_share_1e5=0.99)
 
 
 def test_atari_shaped_puct_1024_trees(monkeypatch):
     B = 1024
     obs = np.random.default_rng(4).standard_normal((B, 128)).astype(np.float32)
     # 601-bin float32 expectations: two float32 evaluators agree to about 300 * 6e-8 * a few = 5e-5
-    _full_size('atari-shaped', ATARI_LIKE, False, 18, 200, 1, 0.997, B, obs, lambda e: e.search_mfma(), True, 0.88, 5e-5,
-               1e-4, monkeypatch)
+    _full_size('atari-shaped', ATARI_LIKE, False, 18, 200, 1, 0.997, B, obs, lambda e: e.search_mfma(), True, 0.99, 5e-5,
+               1e-4, monkeypatch, root_median=1e-5, root_share_1e5=0.5)

@@ -167,3 +167,55 @@ def test_tictactoe_device_env_matches_checker_on_random_play():
                 obs = np.concatenate([np.zeros(18), -np.ones(9)]); lg = np.ones(9)
             assert np.array_equal(cur[b], obs.astype(np.float32)) and np.array_equal(legal[b], lg.astype(np.uint8))
     sp.engine.close()
+
+
+def test_cartpole_selfplay_at_the_benchmarked_size():
+    """The self-play step that the throughput figure is quoted on - 8 192 CartPole environments per GPU, 50 PUCT
+    simulations, fused action + environment kernel writing the device move log (self_play.py:99-113 per environment) -
+    checked by its properties at that size: every transition of a 256-environment sample (first, last and spread
+    environments) is the checker's CartPole step from the state before it; every row of the move log equals the
+    per-step outputs of the same move, for all environments; the games the device lists are the episode ends the host
+    counted, and their lengths add up."""
+    import bench
+    from muzero_amd.self_play import BatchedSelfPlay
+    from muzero_amd.network import MuZeroNetwork
+    from oracle import oracle as orc
+    B, N = 8192, 48
+    cfg = bench.search_config(False, 2, 50, 1, 0.997)
+    cfg.max_moves = 500
+    sp = BatchedSelfPlay(cfg, 'cartpole', MuZeroNetwork(bench.cartpole_net_config(), seed=0), B, seed=3)
+    assert sp.mode == 'fused'
+    L = orc.lib()
+    sample = np.unique(np.concatenate([np.arange(0, B, B // 250), [1, 63, 64, B - 65, B - 64, B - 1]]))
+    log = sp.record(N)
+    state = sp.envs.state.cpu().numpy().copy()
+    ends = np.zeros(B, np.int64)
+    for k in range(N):
+        out = sp.step(1.0)
+        new_state = sp.envs.state.cpu().numpy()
+        act, done = out['action'].cpu().numpy(), out['done'].cpu().numpy()
+        ends += done != 0
+        for b in sample:
+            s = state[b].copy()
+            rew, obs = C.c_double(), np.zeros(4, np.float32)
+            term = L.orc_cartpole_step(s.ctypes.data_as(C.c_void_p), int(act[b]), C.byref(rew), obs.ctypes.data_as(C.c_void_p))
+            assert float(out['reward'][b]) == rew.value
+            if done[b]:
+                assert term or int(sp.envs.moves[b]) == 0
+                assert np.all(np.abs(new_state[b]) <= 0.05)      # restarted from a fresh initial state
+            else:
+                assert not term
+                np.testing.assert_allclose(new_state[b], s, rtol=0, atol=1e-12)
+        # the log's row of this move against the step's own outputs, every environment
+        assert torch.equal(log.observations[k], out['obs_before'].reshape(B, -1))
+        assert torch.equal(log.actions[k], out['action']) and torch.equal(log.to_plays[k], out['to_play'])
+        assert torch.equal(log.rewards[k], out['reward'].to(torch.float64))
+        assert torch.equal(log.root_values[k], out['value']) and torch.equal(log.probs[k], out['probs'])
+        assert torch.equal(log.done[k], out['done'])
+        state = new_state.copy()
+    assert ends.sum() > B // 4                                     # episodes did end inside the window
+    store = sp.harvest()
+    assert len(store) == int(ends.sum())
+    assert int(store.lengths.sum()) <= B * N and int(store.lengths.min()) >= 1
+    # a game's positions are rows of the log: the first listed game of environment 0 starts at its row 0
+    sp.engine.close()
