@@ -276,6 +276,8 @@ def main():
                 os.environ.get('MZ_TREE_REG', '1') != '0')
     one_call = os.environ.get('MZ_BENCH_CALLS', 'act')   # 'move' | 'act' | 'separate': how many launches make a step
 
+    gathered = [0]   # rows of the last per-move gather on this rank (all ranks' environments on the replay rank)
+
     def step(i=None):
         if leaf == 'dropin':
             if i is not None:
@@ -297,7 +299,9 @@ def main():
             out = sp.step(temperature)
             if i is not None:
                 ev[i][1].record()
-            gatherer.gather(out)  # this move's records to the replay rank (a no-op on one rank)
+            full = gatherer.gather(out)  # this move's records to the replay rank (a no-op on one rank)
+            if full is not None:
+                gathered[0] = int(full['action'].shape[0])
             return out
         if leaf == 'mlp' and reg_tree and one_call == 'move':   # roots, simulations, final action rule: one call
             if i is not None:
@@ -411,7 +415,7 @@ def main():
         'mean_leaf_depth': node_visits / (B * S) - 1.0,
         'env_steps_per_sec': (world * B * n_steps / elapsed) if leaf == 'selfplay' else None,
         'recording': ({'where': 'device move log, written by k_act_env', 'games_recorded_rank0': games_recorded,
-                       'moves_recorded_rank0': B * n_steps} if leaf == 'selfplay' else None),
+                       'moves_recorded_rank0': B * n_steps, 'gathered_rows_per_move_rank0': gathered[0]} if leaf == 'selfplay' else None),
         'roofline': {'bound': 'hbm', 'kernel': {'mlp': 'k_search_reg' if reg_tree else 'k_search_net', 'hash': 'k_search_hash', 'step': 'k_select+leaf evaluation+k_expand_backup',
                                 'mfma': ('k_search_gcache' if gumbel and A == 9 else 'k_net_level_rows (one per network level) + k_leaf_backup_select, per simulation' if A > 16 else 'k_search_mfma'), 'mfma_step': ('k_stage_inputs + k_net_level_rows x levels + k_net_epilogue + k_backup_select, per simulation' if A > 16 else 'k_net_step+k_backup_select'), 'step5': 'k_select+leaf evaluation+k_expand_backup', 'dropin': 'MCTS.search (root inference on the level kernels, k_search_mfma, host copies)', 'dropin_batch': 'MCTS.search_batch (root noise from np.random, root inference on the level kernels, k_search_gcache, host copies)',
                                 'selfplay': 'k_begin_net+k_search_reg+k_act_env'}[leaf],

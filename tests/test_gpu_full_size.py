@@ -30,7 +30,7 @@ TICTACTOE, CARTPOLE, ATARI_LIKE = bench.tictactoe_net_config(), bench.cartpole_n
 def _explain(cfg, packed, trees, idx, legal, tp, seed, tid0, g, tol, hidden_tol, net):
     """Trees `idx` (exports in `trees`): the checker rebuilds each from its own stored leaf outputs, and those outputs are
     within tolerance of the checker's dense executor on the same (parent state, action).  Next hidden states: always
-    at the conditioned bound (difference times the range of the scaled plane <= 5e-6), and directly at `hidden_tol`
+    at the conditioned bound (difference times the range of the scaled plane <= 2e-6; measured 2e-7 .. 7e-7), and directly at `hidden_tol`
     where the planes are wide enough for that (None: boards, whose 9-cell planes can be nearly flat)."""
     from oracle import oracle as orc
     S = cfg.simulations
@@ -47,7 +47,7 @@ def _explain(cfg, packed, trees, idx, legal, tp, seed, tid0, g, tol, hidden_tol,
             assert np.abs(nh - t['hidden_states'][1:].reshape(S, -1)).max() <= hidden_tol, b
         err = hidden_conditioned_error(net, t['hidden_states'][par].reshape(S, -1), act, t['hidden_states'][1:].reshape(S, -1))
         worst_h = max(worst_h, err)
-        assert err <= 5e-6, (b, err)
+        assert err <= 2e-6, (b, err)
     print(f'   next hidden states of {len(idx)} trees: largest difference x plane range {worst_h:.2e}')
 
 
@@ -149,18 +149,18 @@ def test_tictactoe_gumbel_16384_trees(monkeypatch):
     # The per-plane min-max scaling of a hidden state (9 cells) amplifies last-bit differences of a nearly flat plane, and
     # these searches run 15 levels deep, so two float32 evaluators drift apart along a chain: hidden states are bounded
     # where they are well conditioned (difference x plane range), the share of identical trees at what was measured
-    # (0.9796) less 0.01, and root values (means over 100 leaf values) by their median (measured 3e-5) and by the
-    # share within 1e-5; the outliers at 5e-3.  What is exact is checked exactly: every leaf output within 1e-5 of the
+    # (0.9796) less 0.01, and root values (means over 100 leaf values) by their median (measured 2.9e-5) and by the
+    # share within 1e-5 (measured 0.29); the outliers at 5e-3.  What is exact is checked exactly: every leaf output within 1e-5 of the
     # checker's on the SAME stored inputs, and the trees rebuilt bit for bit from the stored outputs.
     _full_size('tictactoe', TICTACTOE, True, 9, 100, 2, 1, B, obs, lambda e: e.search_mfma(), True, 0.97, 1e-5, None,
-               monkeypatch, root_tol=5e-3, root_median=1e-4, root_share_1e5=0.25)
+               monkeypatch, root_tol=5e-3, root_median=1e-4, root_share_1e5=0.27)
 
 
 def test_cartpole_puct_8192_trees(monkeypatch):
     B = 8192
     obs = np.random.default_rng(3).uniform(-0.05, 0.05, size=(B, 4)).astype(np.float32)
     _full_size('cartpole', CARTPOLE, False, 2, 50, 1, 0.997, B, obs, lambda e: e.search_net(), False, 0.99, 1e-5, 1e-4,
-               monkeypatch, root_median=1e-6, root_share_1e5=0.99)
+               monkeypatch, root_median=1e-6, root_share_1e5=0.999)
 
 
 def test_atari_shaped_puct_1024_trees(monkeypatch):
@@ -168,4 +168,4 @@ def test_atari_shaped_puct_1024_trees(monkeypatch):
     obs = np.random.default_rng(4).standard_normal((B, 128)).astype(np.float32)
     # 601-bin float32 expectations: two float32 evaluators agree to about 300 * 6e-8 * a few = 5e-5
     _full_size('atari-shaped', ATARI_LIKE, False, 18, 200, 1, 0.997, B, obs, lambda e: e.search_mfma(), True, 0.99, 5e-5,
-               1e-4, monkeypatch, root_median=1e-5, root_share_1e5=0.5)
+               1e-4, monkeypatch, root_median=2e-6, root_share_1e5=0.99)
