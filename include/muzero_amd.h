@@ -319,6 +319,10 @@ typedef struct mz_move_log {
     double *root_values;   /* [capacity][n_envs] */
     double *probs;         /* [capacity][n_envs][n_actions] */
     uint8_t *done;         /* [capacity][n_envs] 1 = the game ended with this move */
+    const uint8_t *open_at_start; /* [n_envs] or NULL. 1 = the environment was in the middle of a game when row 0 was
+                                   * written: its moves up to the first end-of-game flag are the tail of a game that began
+                                   * before this window and are not listed as a game (SelfPlay.play stores whole games
+                                   * only, self_play.py:77-115).  NULL = every environment started a game at row 0. */
 } mz_move_log;
 
 /* mz_act_env_step that also appends every environment's record to row `row` of `log_h` (0 <= row < capacity).
@@ -331,7 +335,8 @@ int mz_act_env_step_log(mz_ctx *ctx, const mz_env_state *env_h, const mz_move_lo
 /* The finished games inside rows [0, n_rows) of a log, environment by environment and in playing order inside an
  * environment (the batched counterpart of the game list a replay buffer accumulates, replay_buffer.py:30-57).
  * mz_log_count_games: out_count i32[n_envs] = games of each environment that ended inside the rows (moves after an
- * environment's last finished game belong to a game still open and are not listed).
+ * environment's last finished game belong to a game still open and are not listed; so are, with open_at_start, the
+ * moves before the first end of a game that was already running when the window opened).
  * mz_log_list_games: first_game i64[n_envs] = exclusive prefix sum of those counts (the caller's scan);
  * out_base i64[G] = index of a game's first position, out_len i32[G] = its length; position i of game g is at
  * index out_base[g] + i * n_envs of the log's per-move arrays (see mz_trajectories.game_base). */

@@ -303,7 +303,9 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     d.discount = cfg->discount; d.c_visit = cfg->c_visit; d.c_scale = cfg->c_scale;
     d.seed = cfg->seed;
     void *unused = nullptr;
-    if (scratch_for_device(cfg->device, &unused) != MZ_OK) { mz_destroy(c); return nullptr; }  // set-up, once per device
+    // set-up, once per device, while that device is current.  Best effort: a context whose callers never use
+    // mz_expand_backup_net_static works without the array, and that entry point repeats the lookup and reports the failure.
+    (void)scratch_for_device(cfg->device, &unused);
     return c;
 }
 
@@ -1262,7 +1264,7 @@ struct MfmaSlot {
     bool *tile_fits;
 };
 
-static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
+static int upload_mfma(mz_ctx *c, const char *fn, const MfmaSlot &slot, const int32_t *steps_h, int32_t n_steps, int32_t n_levels,
                        const int32_t *sched_h, int32_t n_sched, const float *wfrag_h, int64_t n_w,
                        const float *bias_h, int32_t n_b, const int32_t *ctinfo_h, int32_t n_jobs,
                        const int32_t *kidx_h, int32_t n_kidx, int32_t stride, int32_t plane_major,
@@ -1270,27 +1272,29 @@ static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, 
 {
     if (!steps_h || !sched_h || !wfrag_h || !bias_h || !ctinfo_h || !kidx_h || !io_h || n_steps < 1 ||
         n_sched < 4 || n_levels < 1 || n_jobs < 1 || n_kidx < 1)
-        return fail(MZ_ERR_ARG, "mz_set_network_mfma: null/empty program");
+        return fail(MZ_ERR_ARG, std::string(fn) + ": null/empty program");
     if (io_h[6] != c->cfg.hidden_size || io_h[7] != c->cfg.n_actions)
-        return fail(MZ_ERR_ARG, "mz_set_network_mfma: network hidden size / action count differ from the context's");
-    if (io_h[10] < 1 || io_h[6] % io_h[10]) return fail(MZ_ERR_ARG, "mz_set_network_mfma: hidden size not divisible by normalisation groups");
-    if (plane_major && io_h[10] < 8) return fail(MZ_ERR_ARG, "mz_set_network_mfma: plane-major storage needs at least 8 normalisation groups (channels)");
-    if (stride % 8 != 4) return fail(MZ_ERR_ARG, "mz_set_network_mfma: stride must be 4 times an odd number");
-    if (stride > (1 << 20)) return fail(MZ_ERR_ARG, "mz_set_network_mfma: unreasonable activation row");
-    if (n_w < 1 || n_w > (1 << 28) || n_b < 1) return fail(MZ_ERR_ARG, "mz_set_network_mfma: weight or bias array out of range");
+        return fail(MZ_ERR_ARG, std::string(fn) + ": network hidden size / action count differ from the context's");
+    if (io_h[10] < 1 || io_h[6] % io_h[10]) return fail(MZ_ERR_ARG, std::string(fn) + ": hidden size not divisible by normalisation groups");
+    if (plane_major && io_h[10] < 8) return fail(MZ_ERR_ARG, std::string(fn) + ": plane-major storage needs at least 8 normalisation groups (channels)");
+    if (stride % 8 != 4) return fail(MZ_ERR_ARG, std::string(fn) + ": stride must be 4 times an odd number");
+    if (stride > (1 << 20)) return fail(MZ_ERR_ARG, std::string(fn) + ": unreasonable activation row");
+    if (n_w < 1 || n_w > (1 << 28) || n_b < 1) return fail(MZ_ERR_ARG, std::string(fn) + ": weight or bias array out of range");
     for (int s = 0; s < n_steps; s++) {
         const int32_t *st = steps_h + 12 * s;
         int k16 = st[2], nct = st[9];
         if (st[3] < 0 || st[3] + k16 * 16 > stride || st[4] < 0 || st[4] + nct * 16 > stride || st[5] + nct * 16 > stride ||
             st[8] < 0 || st[8] + nct * 16 > n_b || st[10] < 0 || st[10] + nct > n_jobs)
-            return fail(MZ_ERR_ARG, "mz_set_network_mfma: a step addresses outside its buffers");
+            return fail(MZ_ERR_ARG, std::string(fn) + ": a step addresses outside its buffers");
         for (int ct = 0; ct < nct; ct++) {
             const int32_t *job = ctinfo_h + 3 * (st[10] + ct);
             if (job[0] < 0 || job[2] < 0 || (int64_t)job[0] + (int64_t)job[2] * 256 > n_w || job[1] < 0 || job[1] + job[2] > n_kidx)
-                return fail(MZ_ERR_ARG, "mz_set_network_mfma: a column tile addresses outside the weight blocks");
+                return fail(MZ_ERR_ARG, std::string(fn) + ": a column tile addresses outside the weight blocks");
+            // a tile's blocks: each inside the layer's inputs, strictly ascending (hence at most k16 of them) - the level
+            // kernel sizes its rounds of weight loads by the widest layer and would drop the blocks of a longer list
             for (int i = 0; i < job[2]; i++)
-                if (kidx_h[job[1] + i] < 0 || kidx_h[job[1] + i] >= k16)
-                    return fail(MZ_ERR_ARG, "mz_set_network_mfma: a weight block lies outside its layer's inputs");
+                if (kidx_h[job[1] + i] < 0 || kidx_h[job[1] + i] >= k16 || (i > 0 && kidx_h[job[1] + i] <= kidx_h[job[1] + i - 1]))
+                    return fail(MZ_ERR_ARG, std::string(fn) + ": a column tile's weight blocks must be distinct, ascending and inside its layer's inputs");
         }
     }
     // the two per-wave schedules: job ranges in order, at most 64 jobs per wave, every descriptor inside its buffers
@@ -1300,7 +1304,7 @@ static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, 
         const int64_t o_start = sched_h[2 * k], o_desc = sched_h[2 * k + 1];
         const int64_t lim_desc = k == 0 ? sched_h[2] : n_sched;
         if (o_start < 4 || o_start + (int64_t)nw * (n_levels + 1) > o_desc || o_desc > lim_desc || lim_desc > n_sched)
-            return fail(MZ_ERR_ARG, "mz_set_network_mfma: inconsistent schedule offsets");
+            return fail(MZ_ERR_ARG, std::string(fn) + ": inconsistent schedule offsets");
         const int32_t *ws = sched_h + o_start, *wd = sched_h + o_desc;
         const int64_t n_wd = (lim_desc - o_desc) / MZ_DESC_INTS;
         sched_ok[k] = n_wd > 0;
@@ -1308,11 +1312,11 @@ static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, 
         for (int w = 0; w < nw; w++) {
             for (int l = 0; l <= n_levels; l++) {
                 const int64_t v = ws[w * (n_levels + 1) + l];
-                if (v < prev || v > n_wd) return fail(MZ_ERR_ARG, "mz_set_network_mfma: schedule job ranges out of order");
+                if (v < prev || v > n_wd) return fail(MZ_ERR_ARG, std::string(fn) + ": schedule job ranges out of order");
                 prev = v;
             }
             if (ws[w * (n_levels + 1) + n_levels] - ws[w * (n_levels + 1)] > 64)
-                return fail(MZ_ERR_ARG, "mz_set_network_mfma: more than 64 jobs for one wave");
+                return fail(MZ_ERR_ARG, std::string(fn) + ": more than 64 jobs for one wave");
         }
         for (int64_t j = 0; j < n_wd; j++) {
             const int32_t *q = wd + MZ_DESC_INTS * j;
@@ -1320,11 +1324,11 @@ static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, 
                             q[2] >= 0 && q[2] <= 2 && (k == 0 || q[2] == 1) && q[3] >= 0 && q[3] + 16 <= stride &&
                             q[4] >= 0 && q[4] + 16 <= stride && q[5] + 16 <= stride && q[6] >= 0 && q[6] <= 2 &&
                             q[7] >= 0 && q[8] >= 1 && q[8] <= 16 && q[7] + q[8] <= n_b && q[9] >= 0 && q[9] + q[1] <= n_kidx;
-            if (!ok) return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad schedule entry");
+            if (!ok) return fail(MZ_ERR_ARG, std::string(fn) + ": bad schedule entry");
             for (int i = 0; i < q[1] && i < 12; i++) {
                 const int kb = (q[10 + i / 4] >> (8 * (i % 4))) & 0xff;
                 if (q[3] + kb * 16 + 16 > stride || kb != kidx_h[q[9] + i])
-                    return fail(MZ_ERR_ARG, "mz_set_network_mfma: a schedule entry reads outside the activation row");
+                    return fail(MZ_ERR_ARG, std::string(fn) + ": a schedule entry reads outside the activation row");
             }
         }
     }
@@ -1336,18 +1340,18 @@ static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, 
             const int32_t *st = steps_h + 12 * s;
             if (st[0] != l) continue;
             if (l == 0 && (st[3] < io_h[0] || st[3] + st[2] * 16 > stride))
-                return fail(MZ_ERR_ARG, "mz_set_network_mfma: a first-level step reads outside the network inputs");
+                return fail(MZ_ERR_ARG, std::string(fn) + ": a first-level step reads outside the network inputs");
             if ((size_t)(st[2] * 16 + 4) * 32 * 4 > 160 * 1024)
-                return fail(MZ_ERR_ARG, "mz_set_network_mfma: a layer's inputs for 32 trees exceed LDS");
+                return fail(MZ_ERR_ARG, std::string(fn) + ": a layer's inputs for 32 trees exceed LDS");
             for (int ct = 0; ct < st[9]; ct += MZ_LVL_WAVES) {
                 const int n = std::min(MZ_LVL_WAVES, st[9] - ct);
                 // everything a block needs, flattened: step fields + per-wave weight block lists
                 int32_t q[MZ_LVL_DESC] = {st[2] * 16, st[3], st[1], st[4], st[5], st[6], st[8], n, ct, 1};
                 for (int w = 0; w < n; w++) {
-                    if (st[10] + ct + w >= n_jobs) return fail(MZ_ERR_ARG, "mz_set_network_mfma: column tile table too short");
+                    if (st[10] + ct + w >= n_jobs) return fail(MZ_ERR_ARG, std::string(fn) + ": column tile table too short");
                     const int32_t *cj = ctinfo_h + 3 * (st[10] + ct + w);
                     if (cj[1] < 0 || cj[2] < 0 || cj[1] + cj[2] > n_kidx)
-                        return fail(MZ_ERR_ARG, "mz_set_network_mfma: column tile reads outside the block index list");
+                        return fail(MZ_ERR_ARG, std::string(fn) + ": column tile reads outside the block index list");
                     q[10 + 3 * w] = cj[0] * 4; q[11 + 3 * w] = cj[2]; q[12 + 3 * w] = cj[1];
                     for (int i = 0; i < cj[2]; i++) if (kidx_h[cj[1] + i] != i) q[9] = 0;
                 }
@@ -1357,9 +1361,13 @@ static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, 
         job0.push_back((int)(desc.size() / MZ_LVL_DESC));
     }
     for (int s2 = 0; s2 < n_steps; s2++)
-        if (steps_h[12 * s2] < 0 || steps_h[12 * s2] >= n_levels) return fail(MZ_ERR_ARG, "mz_set_network_mfma: bad level");
+        if (steps_h[12 * s2] < 0 || steps_h[12 * s2] >= n_levels) return fail(MZ_ERR_ARG, std::string(fn) + ": bad level");
     for (int i = 0; i < 10; i++) if (slot.bufs[i]) { (void)hipFree(slot.bufs[i]); slot.bufs[i] = nullptr; }
-    *slot.level_job0 = job0;
+    // the slot describes no program until every buffer of the new one is in place: a failure below leaves it empty
+    // (every user checks `steps`), not pointing at freed memory
+    memset(slot.mnet, 0, sizeof *slot.mnet);
+    slot.level_job0->clear();
+    *slot.tile_fits = false;
     *slot.max_k16 = 1;
     for (int s2 = 0; s2 < n_steps; s2++) *slot.max_k16 = std::max(*slot.max_k16, (int)steps_h[12 * s2 + 2]);
     slot.mnet->sched_ok8 = sched_ok[0]; slot.mnet->sched_ok4 = sched_ok[1];
@@ -1393,6 +1401,7 @@ static int upload_mfma(mz_ctx *c, const MfmaSlot &slot, const int32_t *steps_h, 
     m.plane_major = plane_major ? 1 : 0;
     m.n_steps = n_steps; m.n_levels = n_levels; m.stride = stride;
     memcpy(m.io, io_h, sizeof m.io);
+    *slot.level_job0 = job0;
     return MZ_OK;
 }
 
@@ -1406,15 +1415,15 @@ extern "C" int mz_set_network_mfma(mz_ctx *c, const int32_t *steps_h, int32_t n_
     int rc = check_ctx(c, "mz_set_network_mfma");
     if (rc) return rc;
     const MfmaSlot slot{&c->mnet, c->mnet_bufs, &c->mnet_max_k16, &c->mnet_level_job0, &c->mnet_tile_fits};
-    rc = upload_mfma(c, slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
+    rc = upload_mfma(c, "mz_set_network_mfma", slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
                      kidx_h, n_kidx, stride, plane_major, io_h);
     c->chain_ok = -1; c->chain_G = 0;   // the chained search's work lists belong to the program just replaced
     if (rc == MZ_OK) {
         c->mnet_steps_h.assign(steps_h, steps_h + (size_t)n_steps * 12);
         c->mnet_ctinfo_h.assign(ctinfo_h, ctinfo_h + (size_t)n_jobs * 3);
         c->mnet_kidx_h.assign(kidx_h, kidx_h + n_kidx);
-    } else {
-        c->mnet_steps_h.clear();
+    } else if (!c->mnet.steps) {
+        c->mnet_steps_h.clear();   // the upload failed after the old program was released
     }
     return rc;
 }
@@ -1431,7 +1440,7 @@ extern "C" int mz_set_root_network_mfma(mz_ctx *c, int32_t part, const int32_t *
     RootMfma &r = c->rootm[part];
     bool unused = false;
     const MfmaSlot slot{&r.mnet, r.bufs, &r.max_k16, &r.level_job0, &unused};
-    return upload_mfma(c, slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
+    return upload_mfma(c, "mz_set_root_network_mfma", slot, steps_h, n_steps, n_levels, sched_h, n_sched, wfrag_h, n_w, bias_h, n_b, ctinfo_h, n_jobs,
                        kidx_h, n_kidx, stride, plane_major, io_h);
 }
 
@@ -1660,7 +1669,7 @@ extern "C" int mz_log_count_games(const mz_move_log *log, int32_t n_rows, int32_
     if (rc) return rc;
     if (!out_count) return fail(MZ_ERR_ARG, "mz_log_count_games: null output");
     hipLaunchKernelGGL(k_log_games<false>, dim3((log->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, log->done,
-                       (int)log->n_envs, (int)n_rows, out_count, (const long long *)nullptr, (long long *)nullptr,
+                       log->open_at_start, (int)log->n_envs, (int)n_rows, out_count, (const long long *)nullptr, (long long *)nullptr,
                        (int32_t *)nullptr);
     return launch_status("mz_log_count_games");
 }
@@ -1673,7 +1682,7 @@ extern "C" int mz_log_list_games(const mz_move_log *log, int32_t n_rows, const i
     if (rc) return rc;
     if (!first_game || !out_base || !out_len) return fail(MZ_ERR_ARG, "mz_log_list_games: null argument");
     hipLaunchKernelGGL(k_log_games<true>, dim3((log->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, log->done,
-                       (int)log->n_envs, (int)n_rows, (int32_t *)nullptr, reinterpret_cast<const long long *>(first_game),
+                       log->open_at_start, (int)log->n_envs, (int)n_rows, (int32_t *)nullptr, reinterpret_cast<const long long *>(first_game),
                        reinterpret_cast<long long *>(out_base), out_len);
     return launch_status("mz_log_list_games");
 }

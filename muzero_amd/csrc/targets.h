@@ -102,18 +102,23 @@ __global__ void k_make_targets(TrajDev tr, int n_samples, const int32_t *game_id
 
 // The finished games of a move log (see mz_move_log): one thread per environment walks its end-of-game flags.
 // LIST = false: count them; LIST = true: write (first position, length) of each, numbered from first_game[env].
+// An environment flagged in open_at_start was mid-game at row 0: the moves up to its first flag are not a game.
 template <bool LIST>
-__global__ void k_log_games(const uint8_t *done, int n_envs, int n_rows, int32_t *out_count, const long long *first_game,
-                            long long *out_base, int32_t *out_len)
+__global__ void k_log_games(const uint8_t *done, const uint8_t *open_at_start, int n_envs, int n_rows, int32_t *out_count,
+                            const long long *first_game, long long *out_base, int32_t *out_len)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_envs) return;
     int n = 0, start = 0;
     long long g = LIST ? first_game[b] : 0;
+    bool whole = !(open_at_start && open_at_start[b]);   // false while the walk is inside the tail of an earlier game
     for (int k = 0; k < n_rows; k++) {
         if (done[(long long)k * n_envs + b]) {
-            if constexpr (LIST) { out_base[g] = (long long)start * n_envs + b; out_len[g] = k - start + 1; g++; }
-            n++;
+            if (whole) {
+                if constexpr (LIST) { out_base[g] = (long long)start * n_envs + b; out_len[g] = k - start + 1; g++; }
+                n++;
+            }
+            whole = true;
             start = k + 1;
         }
     }

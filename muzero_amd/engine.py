@@ -50,7 +50,7 @@ class MzEnvState(C.Structure):
 class MzMoveLog(C.Structure):
     _fields_ = [('capacity', C.c_int32), ('n_envs', C.c_int32), ('obs_size', C.c_int32), ('n_actions', C.c_int32),
                 ('observations', C.c_void_p), ('actions', C.c_void_p), ('rewards', C.c_void_p), ('to_plays', C.c_void_p),
-                ('root_values', C.c_void_p), ('probs', C.c_void_p), ('done', C.c_void_p)]
+                ('root_values', C.c_void_p), ('probs', C.c_void_p), ('done', C.c_void_p), ('open_at_start', C.c_void_p)]
 
 
 ENV_TICTACTOE, ENV_CARTPOLE = 1, 2

@@ -199,13 +199,16 @@ class BatchedSelfPlay:
 
     def record(self, capacity: int) -> MoveLog:
         """Starts a collection window: the next `capacity` moves of every environment go to a device move log
-        (re-used when its size allows).  Games still open when the window starts lose the moves already played."""
+        (re-used when its size allows).  Only whole games are listed afterwards, as SelfPlay.play stores them
+        (self_play.py:77-115): an environment in the middle of a game when the window opens is flagged, and its moves
+        up to the end of that game are skipped by the game list, like the moves after the last finished game."""
         e = self.envs
         if self.log is None or self.log.capacity < capacity:
             shape = (3, 3, 3) if e.kind == 'tictactoe' else (1, 1, 4)
             self.log = MoveLog(capacity, self.B, shape, e.A, self.device)
         self.log.rows = 0
         self.log.done.zero_()
+        torch.ne(e.moves, 0, out=self.log.open_at_start.view(torch.bool))
         return self.log
 
     def stop_recording(self) -> None:

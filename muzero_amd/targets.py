@@ -42,10 +42,13 @@ class MoveLog:
         self.rewards, self.root_values = z(torch.float64), z(torch.float64)
         self.probs = z(torch.float64, self.A)
         self.done = z(torch.uint8)
+        # 1 = the environment was in the middle of a game when the window opened (set by the owner of the environments)
+        self.open_at_start = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
         self.rows = 0   # rows written in the current window
         p = lambda t: t.data_ptr()  # noqa: E731
         self.struct = _engine.MzMoveLog(self.capacity, self.B, self.obs_size, self.A, p(self.observations), p(self.actions),
-                                        p(self.rewards), p(self.to_plays), p(self.root_values), p(self.probs), p(self.done))
+                                        p(self.rewards), p(self.to_plays), p(self.root_values), p(self.probs), p(self.done),
+                                        p(self.open_at_start))
 
     def games(self):
         """(first position, length) of every finished game in the written rows, as device tensors (int64, int32):

@@ -114,6 +114,47 @@ def test_batches_from_the_log_equal_batches_from_host_gathered_games(game):
     sp.engine.close()
 
 
+@pytest.mark.parametrize('game', ['cartpole', 'tictactoe'])
+def test_consecutive_windows_list_whole_games_only(game):
+    """SelfPlay.play stores a game when it has ended, from its first move (self_play.py:77-115).  A window that
+    opens in the middle of a game does not list that game's tail as a game: every listed game begins where an
+    environment was reset, and the games of a second window are the end-of-game flags minus one per environment that
+    was mid-game at its start and finished that game inside it."""
+    B, n_steps = 48, 23
+    sp, cfg, A, shape = _selfplay(game, B, seed=5)
+    sp.play(n_steps)                                   # leaves most environments in the middle of a game
+    open_before = (sp.envs.moves != 0).cpu().numpy()
+    assert open_before.sum() > B // 4
+    sp.record(n_steps)
+    records = []
+    for _ in range(n_steps):
+        out = sp.step(1.0)
+        records.append({k: v.cpu().numpy().copy() for k, v in out.items()})
+    np.testing.assert_array_equal(sp.log.open_at_start.cpu().numpy().astype(bool), open_before)
+    done = np.stack([r['done'] for r in records]).astype(bool)            # [row][env]
+    base, length = (t.cpu().numpy() for t in sp.log.games())
+    host = []                                                             # (first row, env, length) of whole games
+    for b in range(B):
+        start, whole = 0, not open_before[b]
+        for k in range(n_steps):
+            if done[k, b]:
+                if whole:
+                    host.append((start, b, k - start + 1))
+                whole, start = True, k + 1
+    assert len(host) == done.sum() - (open_before & done.any(0)).sum()
+    np.testing.assert_array_equal(base, [r * B + b for r, b, _ in host])
+    np.testing.assert_array_equal(length, [n for _, _, n in host])
+    # a listed game that begins after row 0 begins on the row after an end-of-game flag; one at row 0 in an
+    # environment that had just been reset
+    for r, b, _ in host:
+        assert (r == 0 and not open_before[b]) or done[r - 1, b]
+    if game == 'tictactoe':   # every stored game starts from the empty board
+        store = sp.harvest()
+        first = store.observations[torch.as_tensor(base, device=store.device)].cpu().numpy().reshape(-1, 3, 3, 3)
+        assert not first[:, :2].any()
+    sp.engine.close()
+
+
 def test_play_returns_the_games_of_its_window_and_a_full_log_is_refused():
     from muzero_amd.engine import EngineError
     sp, cfg, A, shape = _selfplay('cartpole', 16, seed=9)
