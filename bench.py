@@ -171,6 +171,9 @@ def main():
     if os.environ.get('MZ_BENCH_TREES'):   # experiments only: another batch size (the line's config says so)
         B = int(os.environ['MZ_BENCH_TREES'])
         desc += f' [experiment: {B} trees]'
+    if os.environ.get('MZ_BENCH_SIMS'):    # experiments only: another simulation count
+        S = int(os.environ['MZ_BENCH_SIMS'])
+        desc += f' [experiment: {S} simulations]'
     leaf_macs = None
     root_on_device = False
     cfg = search_config(gumbel, A, S, players, gamma)
@@ -394,7 +397,7 @@ def main():
         from muzero_amd.build import source_fingerprint
         with open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')) as f:
             entry = json.load(f).get(args.workload)
-        if entry is not None and os.environ.get('MZ_BENCH_TREES') is None:
+        if entry is not None and os.environ.get('MZ_BENCH_TREES') is None and os.environ.get('MZ_BENCH_SIMS') is None:
             if entry.get('kernel_sources') == source_fingerprint():
                 traffic = entry.get('traffic_bytes_per_launch')
             else:
@@ -427,10 +430,14 @@ def main():
     if leaf in ('mfma', 'mfma_step') and leaf_macs is not None:
         # leaves evaluated on the matrix cores: the lowered network's multiply-accumulates (unpadded) per leaf x leaves
         # per launch / the same launch time, against the dense float32 MFMA peak (v_mfma_f32_16x16x4_f32)
-        tf = 2.0 * leaf_macs[0] * B * S / (kern_ms * 1e-3) / 1e12
+        # priced on the multiply-accumulates the matrix instructions execute (zero blocks of lowered convolutions are
+        # skipped, the kept blocks are padded to 16 x 16); the dense-equivalent figure of the unlowered layers rides along
+        tf = 2.0 * leaf_macs[1] * B * S / (kern_ms * 1e-3) / 1e12
+        tf_dense = 2.0 * leaf_macs[0] * B * S / (kern_ms * 1e-3) / 1e12
         out['roofline_mfma'] = {'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                'frac': tf / MFMA_F32_PEAK_TFLOPS, 'flop_per_leaf': 2 * leaf_macs[0],
-                                'executed_flop_per_leaf': 2 * leaf_macs[1],
+                                'frac': tf / MFMA_F32_PEAK_TFLOPS, 'executed_flop_per_leaf': 2 * leaf_macs[1],
+                                'dense_equivalent': {'achieved': tf_dense, 'frac': tf_dense / MFMA_F32_PEAK_TFLOPS,
+                                                     'flop_per_leaf': 2 * leaf_macs[0]},
                                 'note': 'the launch also holds the tree operations of the same simulations'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, net, leaf, A, S, H, B, gumbel)

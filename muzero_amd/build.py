@@ -10,7 +10,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuzero_amd.so')
 OBJ_DIR = os.path.join(HERE, 'build')
 # translation units: the C ABI with the tree / fused-network kernels, and the matrix-core kernels
-SOURCES = ['engine.hip', 'mfma_kernels.hip', 'chain_kernels.hip']
+SOURCES = ['engine.hip', 'mfma_kernels.hip', 'chain_kernels.hip', 'cached_kernels_a.hip', 'cached_kernels_b.hip',
+           'cached_kernels_c.hip']
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'muzero_amd.h')]
 # -ffp-contract=off: the tree arithmetic must round exactly like the reference's NumPy expressions.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17']
@@ -37,9 +38,13 @@ def needs_build(lib: str = LIB) -> bool:
 
 
 # headers a translation unit does NOT include (everything else counts as a dependency)
-NOT_INCLUDED = {'engine.hip': {'net_mfma.h', 'search_cached.h', 'search_chain.h'},
-                'mfma_kernels.hip': {'search_net.h', 'search_reg.h', 'env_step.h', 'targets.h', 'search_chain.h'},
-                'chain_kernels.hip': {'search_net.h', 'search_reg.h', 'env_step.h', 'targets.h', 'search_cached.h'}}
+_TREE_ONLY = {'search_net.h', 'search_reg.h', 'env_step.h', 'targets.h'}
+NOT_INCLUDED = {'engine.hip': {'net_mfma.h', 'search_cached.h', 'search_chain.h', 'cached_launch.h'},
+                'mfma_kernels.hip': _TREE_ONLY | {'search_chain.h', 'cached_launch.h'},
+                'chain_kernels.hip': _TREE_ONLY | {'search_cached.h', 'cached_launch.h'},
+                'cached_kernels_a.hip': _TREE_ONLY | {'search_chain.h'},
+                'cached_kernels_b.hip': _TREE_ONLY | {'search_chain.h'},
+                'cached_kernels_c.hip': _TREE_ONLY | {'search_chain.h'}}
 
 
 def _stale(src: str, obj: str) -> bool:

@@ -728,10 +728,11 @@ static int search_run(mz_ctx *c, int32_t net_kind, const void *net_params_h, con
             if (chained) return search_chained(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
             return search_by_level(c, n_sims, noise, noise_max_calls, (hipStream_t)stream);
         }
-        // Gumbel trees whose record layout the decision-caching kernel is built for (9 actions: the 3x3 board games)
-        // walk down cached decisions and re-decide only the nodes a simulation changed (search_cached.h).
+        // Gumbel trees of up to 16 actions walk down cached decisions and re-decide only the nodes a simulation changed
+        // (search_cached.h): tiles of 32 trees, or of 16 where only those fit in LDS (longer searches, wider networks).
         int ctm = 32;
         if (const char *e = getenv("MZ_SEARCH_TM")) ctm = atoi(e) == 16 ? 16 : 32;
+        else if (c->cfg.gumbel && !search_gcache_supported(c->d, c->mnet, 32) && search_gcache_supported(c->d, c->mnet, 16)) ctm = 16;
         bool cached = c->cfg.gumbel && search_gcache_supported(c->d, c->mnet, ctm);
         if (const char *e = getenv("MZ_SEARCH_CACHED")) {   // 0: never, 2: demanded (tests that must not pass vacuously)
             if (atoi(e) == 2 && !cached)

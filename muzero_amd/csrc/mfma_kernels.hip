@@ -1,4 +1,6 @@
-// The matrix-core kernels (net_mfma.h, search_cached.h) and their launch functions, compiled apart from the C ABI layer.
+// The matrix-core kernels (net_mfma.h) and their launch functions, compiled apart from the C ABI layer; the cached-decision
+// search kernels (search_cached.h) are instantiated in cached_kernels_[abc].hip and dispatched from here.
+#include <algorithm>
 #include <cstdlib>
 #include "search_cached.h"  // net_mfma.h, dense_net.h, tree_kernels.h
 
@@ -104,31 +106,39 @@ bool launch_leaf_backup_select(int rl, bool gumbel, hipStream_t st, const Dev &d
 
 static size_t gcache_dynamic_lds(const Dev &d, const MfmaNet &net, int tm)
 {
-    return ((size_t)net.stride + d.L.N + 2 * d.L.S + 1) * tm * 4;   // activations, decisions, paths, work list
+    // activations (or the record staging of the re-decision phase, one area per wave, where that is larger), decisions,
+    // paths, work list
+    const size_t act = std::max((size_t)net.stride * tm * 4, (size_t)(tm / 4) * MZ_GC_STAGE);
+    return act + ((size_t)d.L.N + 2 * d.L.S + 1) * tm * 4;
 }
 
 bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm)
 {
-    using GL = GumbelLayout<9>;
     const Layout &L = d.L;
-    const bool layout = L.prior_f32 && L.A == 9 && L.idx16 && L.rec == GL::rec && L.off_crew == GL::off_crew &&
-                        L.off_prior == GL::off_prior && L.off_cvis == GL::off_cvis && L.off_cidx == GL::off_cidx;
-    const size_t stat = (size_t)tm * 16 * 8 + (size_t)tm * 9 * 8 + (size_t)tm * 20 + 64;  // the kernel's static arrays
+    // the record the kernels are instantiated for: GumbelLayout<A, 2 or 4> of search_cached.h, here from the run-time A
+    auto ru = [](int x, int m) { return (x + m - 1) / m * m; };
+    const int A = L.A, iw = L.idx16 ? 2 : 4;
+    const int off_crew = 32 + 8 * A, off_prior = off_crew + 8 * A, off_cvis = off_prior + ru(4 * A, 8);
+    const int off_cidx = off_cvis + ru(iw * A, 4), rec = ru(off_cidx + iw * A, 64);
+    const bool layout = L.prior_f32 && A >= 2 && A <= 16 && L.off_cval == 32 && L.rec == rec && L.off_crew == off_crew &&
+                        L.off_prior == off_prior && L.off_cvis == off_cvis && L.off_cidx == off_cidx;
+    const size_t stat = (size_t)tm * 16 * 8 + (size_t)tm * A * 8 + (size_t)tm * 20 + 64;  // the kernel's static arrays
     const bool sched = tm == 32 ? net.sched_ok8 : net.sched_ok4;
-    // the re-decision phase stages records in the (then idle) activations, one area per wave, and addresses a tile's
-    // records by 32-bit offsets
-    const bool stage = (size_t)tm * net.stride * 4 >= (size_t)(tm / 4) * MZ_GC_STAGE && (long long)tm * L.tree_stride < 0x7fffffffLL;
+    // the re-decision phase addresses a tile's records by 32-bit offsets; a work-list entry holds a node number of 22 bits
+    const bool stage = (long long)tm * L.tree_stride < 0x7fffffffLL && L.N < (1 << 22);
     return layout && sched && stage && (tm == 32 || tm == 16) && gcache_dynamic_lds(d, net, tm) + stat <= 160 * 1024;
 }
+
+hipError_t launch_search_gcache_a(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims, size_t lds);
+hipError_t launch_search_gcache_b(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims, size_t lds);
+hipError_t launch_search_gcache_c(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims, size_t lds);
 
 hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims)
 {
     const size_t lds = gcache_dynamic_lds(d, net, tm);
-    auto kern = tm == 32 ? k_search_gcache<32, 9> : k_search_gcache<16, 9>;
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((d.B + tm - 1) / tm), dim3(tm * 16), lds, st, d, net, first_leaf, n_sims);
-    return hipSuccess;
+    if (d.L.A <= 6) return launch_search_gcache_a(tm, st, d, net, first_leaf, n_sims, lds);
+    if (d.L.A <= 11) return launch_search_gcache_b(tm, st, d, net, first_leaf, n_sims, lds);
+    return launch_search_gcache_c(tm, st, d, net, first_leaf, n_sims, lds);
 }
 
 }  // namespace mz

@@ -40,8 +40,9 @@ void launch_net_epilogue(int lanes, hipStream_t st, const Dev &d, const MfmaNet 
 // k_search_mfma<32, rl, gumbel>: the whole simulation loop, every node of the path scored on the way down.
 hipError_t launch_search_mfma(int rl, bool gumbel, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf,
                               int n_sims, const double *noise, int noise_max_calls);
-// k_search_gcache<tm, 9>: the whole simulation loop over cached decisions (Gumbel).  `supported` tells whether the
-// kernel is built for this tree layout and fits in LDS with tm-tree tiles.
+// k_search_gcache<tm, A, row width>: the whole simulation loop over cached decisions (Gumbel, 2..16 actions, records
+// with 16- or 32-bit visit / index rows).  `supported` tells whether the tree layout is one the kernels are built for
+// and everything fits in LDS with tm-tree tiles (tm = 32 or 16).
 bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm);
 hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims);
 // Level by level through global memory: k_stage_inputs, k_net_level_rows (one level for a range of 32-tree tiles),

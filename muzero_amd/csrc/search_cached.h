@@ -25,16 +25,18 @@
 
 namespace mz {
 
-// Record layout of a Gumbel tree with A actions and 16-bit visit / index rows, as mz_create lays it out.
-template <int A>
+// Record layout of a Gumbel tree with A actions and visit / index rows of IW bytes per entry (2 or 4), as mz_create
+// lays it out.
+template <int A, int IW>
 struct GumbelLayout {
+    static_assert(A >= 2 && A <= 16 && (IW == 2 || IW == 4), "one 16-lane group per tree; int16 or int32 rows");
     static constexpr int ru(int x, int m) { return (x + m - 1) / m * m; }
     static constexpr int off_cval = 32;
     static constexpr int off_crew = off_cval + 8 * A;
     static constexpr int off_prior = off_crew + 8 * A;
     static constexpr int off_cvis = off_prior + ru(4 * A, 8);
-    static constexpr int off_cidx = off_cvis + ru(2 * A, 4);
-    static constexpr int rec = ru(off_cidx + 2 * A, 64);
+    static constexpr int off_cidx = off_cvis + ru(IW * A, 4);
+    static constexpr int rec = ru(off_cidx + IW * A, 64);
 };
 
 // np.sum over A values in NumPy's order (numpy/_core/src/umath/loops_utils.h.src pairwise_sum below its block size):
@@ -88,10 +90,12 @@ __device__ __forceinline__ double rec_f64(const uint4 (&ch)[NCH])
 {
     return __builtin_bit_cast(double, ((unsigned long long)rec_word<OFF / 4 + 1>(ch) << 32) | (unsigned long long)rec_word<OFF / 4>(ch));
 }
-template <int OFF, int NCH>
-__device__ __forceinline__ int rec_i16(const uint4 (&ch)[NCH])
+// an entry of the visit / index rows: int16 (IW = 2) or int32 (IW = 4) at byte OFF
+template <int OFF, int IW, int NCH>
+__device__ __forceinline__ int rec_int(const uint4 (&ch)[NCH])
 {
-    return (int)(int16_t)(rec_word<OFF / 4>(ch) >> ((OFF & 3) * 8));
+    if constexpr (IW == 2) return (int)(int16_t)(rec_word<OFF / 4>(ch) >> ((OFF & 3) * 8));
+    else return (int)rec_word<OFF / 4>(ch);
 }
 
 // A decision: the action the selection rule picks at a node and where it leads.
@@ -99,29 +103,29 @@ __device__ __forceinline__ int rec_i16(const uint4 (&ch)[NCH])
 // One lane evaluates one node from its record in global memory.  `gum`: the tree's Gumbel noise [A] (root only),
 // `cv_row`: the tree's sequential-halving schedule (root only).
 // The record as 16-byte chunks in registers (it is 64-byte aligned); every field sits at a compile-time position.
-template <int A>
+template <int A, int IW>
 struct GumbelRec {
-    static constexpr int NCH = (GumbelLayout<A>::off_cidx + 2 * A + 15) / 16;
+    static constexpr int NCH = (GumbelLayout<A, IW>::off_cidx + IW * A + 15) / 16;
     uint4 ch[NCH];
 };
 
 // Loads the chunks of `mask` (bit k = bytes 16 k .. 16 k + 15 of the record).
-template <int A>
-__device__ __forceinline__ void rec_load(GumbelRec<A> &r, const char *rec, unsigned mask)
+template <int A, int IW>
+__device__ __forceinline__ void rec_load(GumbelRec<A, IW> &r, const char *rec, unsigned mask)
 {
     const uint4 *src = reinterpret_cast<const uint4 *>(rec);
-    static_for<GumbelRec<A>::NCH>([&](auto K) {
+    static_for<GumbelRec<A, IW>::NCH>([&](auto K) {
         constexpr int k = decltype(K)::value;
         if ((mask >> k) & 1u) r.ch[k] = src[k];
     });
 }
 
-template <int A>
-__device__ __forceinline__ int gumbel_decide(const Dev &d, const GumbelRec<A> &rec, bool is_root, unsigned long long legal,
+template <int A, int IW>
+__device__ __forceinline__ int gumbel_decide(const Dev &d, const GumbelRec<A, IW> &rec, bool is_root, unsigned long long legal,
                                              const double *gum, const int32_t *cv_row, long long *ld_cycles = nullptr)
 {
-    using GL = GumbelLayout<A>;
-    constexpr int NCH = GumbelRec<A>::NCH;
+    using GL = GumbelLayout<A, IW>;
+    constexpr int NCH = GumbelRec<A, IW>::NCH;
     const uint4 (&ch)[NCH] = rec.ch;
 #ifdef MZ_STAMPS
     const long long ld_t0 = clock64();
@@ -138,8 +142,8 @@ __device__ __forceinline__ int gumbel_decide(const Dev &d, const GumbelRec<A> &r
         const double v = rec_f64<GL::off_cval + 8 * a>(ch), r = rec_f64<GL::off_crew + 8 * a>(ch);
         q[a] = r + d.discount * v;                                     // Tree.qvalues, mcts/tree.py:55-58
         pf[a] = __builtin_bit_cast(float, rec_word<(GL::off_prior + 4 * a) / 4>(ch));
-        cv[a] = rec_i16<GL::off_cvis + 2 * a>(ch);
-        ci[a] = rec_i16<GL::off_cidx + 2 * a>(ch);
+        cv[a] = rec_int<GL::off_cvis + IW * a, IW>(ch);
+        ci[a] = rec_int<GL::off_cidx + IW * a, IW>(ch);
         vsum += cv[a];
         vmax = cv[a] > vmax ? cv[a] : vmax;
     });
@@ -339,20 +343,22 @@ __device__ __forceinline__ void pool_locate(const PoolScan &p, int item, int *tr
 
 // The records of a wave's 64 work-list nodes, fetched so that the memory pipeline sees whole cache lines: with one lane
 // per node every 16-byte load of a wave touches 64 different lines (64 tag look-ups per instruction: the re-decision
-// phase spent half its time there).  Here 8 lanes read the 128 bytes of one line, 8 records per instruction, the wave
-// parks the lines in LDS and every lane reads its own record's chunks back; the record's two lines take turns in the
-// same staging area.  `stage`: MZ_GC_STAGE bytes of LDS owned by the wave (the tile's activations, idle in this phase:
-// the caller zeroes them again afterwards), `off`: byte offset of the lane's record from `base`, negative = no record.
-#define MZ_GC_STAGE (64 * 144 + 256)   // 64 lines of 128 bytes, 16 bytes apart (conflict-free 16-byte reads) + 64 offsets
-template <int A>
-__device__ __forceinline__ void rec_fetch_staged(GumbelRec<A> &r, const char *base, int off, char *stage, int lane,
+// phase spent half its time there).  Here 8 lanes read 128 consecutive bytes of one record, 8 records per instruction,
+// the wave parks them in LDS and every lane reads its own record's chunks back; the record's 128-byte pieces (one to
+// four of them) take turns in the same staging area, the loads of the next piece in flight while this one is read back.
+// `stage`: MZ_GC_STAGE bytes of LDS owned by the wave (the tile's activations, idle in this phase: the caller zeroes
+// them again afterwards), `off`: byte offset of the lane's record from `base`, negative = no record.
+#define MZ_GC_STAGE (64 * 144 + 256)   // 64 pieces of 128 bytes, 16 bytes apart (conflict-free 16-byte reads) + 64 offsets
+template <int A, int IW>
+__device__ __forceinline__ void rec_fetch_staged(GumbelRec<A, IW> &r, const char *base, int off, char *stage, int lane,
                                                  long long *stamps = nullptr)
 {
 #ifdef MZ_STAMPS
     const long long ft0 = clock64();
 #endif
-    constexpr int NCH = GumbelRec<A>::NCH;
-    static_assert(NCH > 8 && NCH <= 16, "a record of two 128-byte lines");
+    constexpr int NCH = GumbelRec<A, IW>::NCH;
+    constexpr int NP = (NCH + 7) / 8;                         // 128-byte pieces that hold fields
+    constexpr int REC_CH = GumbelLayout<A, IW>::rec / 16;      // 16-byte chunks of a whole record
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: arrays of it become registers
     int32_t *offs = reinterpret_cast<int32_t *>(stage + 64 * 144);
     u32x4 *st = reinterpret_cast<u32x4 *>(stage);
@@ -362,34 +368,45 @@ __device__ __forceinline__ void rec_fetch_staged(GumbelRec<A> &r, const char *ba
     int so[8];
     u32x4 ln[8];
     static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; so[k] = offs[8 * k + grp] + 16 * sub; });
-    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; ln[k] = *reinterpret_cast<const u32x4 *>(base + so[k]); });
+    // chunk 8 p + sub of the record; the last piece of a record that ends inside it reads chunk 0 again instead of the
+    // bytes behind the record (the last record of the last tree has nothing behind it)
+    auto fetch = [&](auto P) {
+        constexpr int p = decltype(P)::value;
+        const int shift = (REC_CH >= 8 * p + 8 || 8 * p + sub < REC_CH) ? 128 * p : -16 * sub;
+        static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; ln[k] = *reinterpret_cast<const u32x4 *>(base + so[k] + shift); });
+    };
+    fetch(std::integral_constant<int, 0>());
     __builtin_amdgcn_sched_barrier(0);   // all eight loads in flight before the first store waits for its data
 #ifdef MZ_STAMPS
     if (stamps) { stamps[0] += clock64() - ft0; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[1] += clock64() - ft0; }
 #endif
-    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; st[(8 * k + grp) * 9 + sub] = ln[k]; });
-    __builtin_amdgcn_sched_barrier(0);
-    // the second lines are on their way during the reads below
-    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; ln[k] = *reinterpret_cast<const u32x4 *>(base + so[k] + 128); });
-    __builtin_amdgcn_sched_barrier(0);
-    lds_fence();
-    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; r.ch[k] = __builtin_bit_cast(uint4, st[lane * 9 + k]); });
-    lds_fence();
-    static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; st[(8 * k + grp) * 9 + sub] = ln[k]; });
-    lds_fence();
-    static_for<NCH - 8>([&](auto K) { constexpr int k = decltype(K)::value; r.ch[8 + k] = __builtin_bit_cast(uint4, st[lane * 9 + k]); });
-    lds_fence();
+    static_for<NP>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        static_for<8>([&](auto K) { constexpr int k = decltype(K)::value; st[(8 * k + grp) * 9 + sub] = ln[k]; });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (p + 1 < NP) {   // the next piece is on its way during the reads below
+            fetch(std::integral_constant<int, p + 1>());
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_fence();
+        constexpr int n = NCH - 8 * p < 8 ? NCH - 8 * p : 8;
+        static_for<n>([&](auto K) { constexpr int k = decltype(K)::value; r.ch[8 * p + k] = __builtin_bit_cast(uint4, st[lane * 9 + k]); });
+        lds_fence();
+    });
 #ifdef MZ_STAMPS
-    if (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamps[2] += clock64() - ft0 + (long long)(r.ch[9].x & 0); }
+    if (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamps[2] += clock64() - ft0 + (long long)(r.ch[NCH - 1].x & 0); }
 #endif
 }
 
 // An entry of the re-decision work list: tree of the tile (5 bits) | node (22 bits).
 __device__ __forceinline__ int item_word(int tree, int node) { return (int)((unsigned)tree << 27 | (unsigned)node); }
 
-// Dynamic LDS: activations [TM][stride] floats | decisions int32 [TM][N] | paths int32 [TM][S] | items int32 [TM][S + 1].
-template <int TM, int A>
-__global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, int first_leaf, int n_sims)
+// Dynamic LDS: activations [TM][stride] floats (at least one record staging area per wave) | decisions int32 [TM][N] |
+// paths int32 [TM][S] | items int32 [TM][S + 1].
+// Two waves per SIMD (256 registers): one 32-tree tile or two 16-tree tiles per compute unit.  (Three 16-tree tiles, 168
+// registers each, only fit in LDS for the shortest searches and were measured slower: the decisions then spill.)
+template <int TM, int A, int IW>
+__global__ __launch_bounds__(TM * 16, 2) void k_search_gcache(Dev d, MfmaNet net, int first_leaf, int n_sims)
 {
     extern __shared__ __align__(16) float act[];
     __shared__ __align__(16) double s_bk[TM * 16];
@@ -401,7 +418,10 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
     const int H = net.io[6], N = d.L.N, S = d.L.S;
     const bool live = t < d.B, on = a < A;
     float *row = act + i * net.stride;
-    int32_t *dec_all = reinterpret_cast<int32_t *>(act + TM * net.stride);
+    // (a narrow network's activations are smaller than the record staging of the re-decision phase, which borrows them)
+    constexpr int stage_floats = (TM / 4) * MZ_GC_STAGE / 4;
+    const int act_floats = TM * net.stride > stage_floats ? TM * net.stride : stage_floats;
+    int32_t *dec_all = reinterpret_cast<int32_t *>(act + act_floats);
     int32_t *path_all = dec_all + TM * N;
     int32_t *item_list = path_all + TM * S;   // the nodes to re-decide after a simulation (item_word below)
     double *bk = s_bk + i * 16;
@@ -430,9 +450,9 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
             int tree, node;
             pool_locate<TM>(ps, base + tid, &tree, &node);
             if (base + tid < ps.total) {
-                GumbelRec<A> r;
-                rec_load<A>(r, tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A>::rec, ~0u);
-                dec_all[tree * N + node] = gumbel_decide<A>(d, r, node == 0, s_legal[tree], s_gum + tree * A,
+                GumbelRec<A, IW> r;
+                rec_load<A, IW>(r, tile_nodes + (long long)tree * d.L.tree_stride + (long long)node * GumbelLayout<A, IW>::rec, ~0u);
+                dec_all[tree * N + node] = gumbel_decide<A, IW>(d, r, node == 0, s_legal[tree], s_gum + tree * A,
                                                             d.cv_table + s_cvoff[tree]);
             }
         }
@@ -548,20 +568,20 @@ __global__ __launch_bounds__(TM * 16) void k_search_gcache(Dev d, MfmaNet net, i
                 const bool has = base + tid < total;
                 const int w = has ? item_list[base + tid] : 0;
                 const int tree = (int)((unsigned)w >> 27), node = w & 0x3fffff;
-                GumbelRec<A> grec;
+                GumbelRec<A, IW> grec;
                 if (base + (wave << 6) >= total) continue;   // wave-uniform: none of the wave's lanes has a node
                 #ifdef MZ_STAMPS
-                rec_fetch_staged<A>(grec, tile_nodes, has ? tree * (int)d.L.tree_stride + node * GumbelLayout<A>::rec : 0, stage, lane, &sx[12]);
+                rec_fetch_staged<A, IW>(grec, tile_nodes, has ? tree * (int)d.L.tree_stride + node * GumbelLayout<A, IW>::rec : 0, stage, lane, &sx[12]);
 #else
-                rec_fetch_staged<A>(grec, tile_nodes, has ? tree * (int)d.L.tree_stride + node * GumbelLayout<A>::rec : 0, stage, lane);
+                rec_fetch_staged<A, IW>(grec, tile_nodes, has ? tree * (int)d.L.tree_stride + node * GumbelLayout<A, IW>::rec : 0, stage, lane);
 #endif
                 if (has) {
 #ifdef MZ_STAMPS
                     sx[11] += clock64() - ph_t0 + node * 0;
-                    dec_all[tree * N + node] = gumbel_decide<A>(d, grec, node == 0, s_legal[tree], s_gum + tree * A,
+                    dec_all[tree * N + node] = gumbel_decide<A, IW>(d, grec, node == 0, s_legal[tree], s_gum + tree * A,
                                                                 d.cv_table + s_cvoff[tree], &sx[5]);
 #else
-                    dec_all[tree * N + node] = gumbel_decide<A>(d, grec, node == 0, s_legal[tree], s_gum + tree * A,
+                    dec_all[tree * N + node] = gumbel_decide<A, IW>(d, grec, node == 0, s_legal[tree], s_gum + tree * A,
                                                                 d.cv_table + s_cvoff[tree]);
 #endif
                 }

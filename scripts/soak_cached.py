@@ -1,8 +1,9 @@
 """Soak test (not part of the suite): the cached-decision Gumbel kernel (certified cheap argmax, work list, staged record
-fetch) against the kernel that scores every node with the reference's operations on the way down.  Random 3x3-board
-ResNets (16 channels, the layout the cached kernel serves), policy heads scaled from nearly flat to sharply peaked so
-that leads of every size occur, random simulations / players / discount / legality / batch and tile sizes.  Every
-root statistic of every tree and a sample of whole trees must agree bit for bit.
+fetch) against the kernel that scores every node with the reference's operations on the way down.  Random action counts
+(2..16: 3x3-board ResNets with 16 channels for 9 actions half of the time, small MLPs otherwise), records with 16- or
+32-bit visit / index rows, policy heads scaled from nearly flat to sharply peaked so that leads of every size occur,
+random simulations / players / discount / legality / batch and tile sizes.  Every root statistic of every tree and a
+sample of whole trees must agree bit for bit.
 
     python scripts/soak_cached.py [seed=1] [trials=30]
 """
@@ -45,10 +46,24 @@ for trial in range(TRIALS):
     S = int(rng.integers(1, 101)); players = int(rng.integers(1, 3)); gamma = float(rng.choice([1.0, 0.997]))
     B = int(rng.integers(1, 300)); L = int(rng.choice([1, 5, 10, 30]))
     red = int(rng.choice([2, 4, 8])); fc = int(rng.choice([8, 16, 32]))
-    ncfg = SimpleNamespace(network='resnet', observation_dim=[3, 3, 3], n_actions=9, n_stacked_observations=1,
-                           blocks=int(rng.integers(1, 3)), channels=16, reduced_channels_reward=red,
-                           reduced_channels_policy=red, reduced_channels_value=red, resnet_fc_reward_layers=[fc],
-                           resnet_fc_policy_layers=[fc], resnet_fc_value_layers=[fc], downsample=False, support_limit=L)
+    A = int(rng.integers(2, 17))
+    if rng.random() < 0.3:
+        A = 9
+    board = A == 9 and rng.random() < 0.5
+    if rng.random() < 0.4:
+        os.environ['MZ_IDX16'] = '0'          # 32-bit rows even where 16 bits would shorten the record
+    else:
+        os.environ.pop('MZ_IDX16', None)
+    if board:
+        ncfg = SimpleNamespace(network='resnet', observation_dim=[3, 3, 3], n_actions=9, n_stacked_observations=1,
+                               blocks=int(rng.integers(1, 3)), channels=16, reduced_channels_reward=red,
+                               reduced_channels_policy=red, reduced_channels_value=red, resnet_fc_reward_layers=[fc],
+                               resnet_fc_policy_layers=[fc], resnet_fc_value_layers=[fc], downsample=False, support_limit=L)
+    else:
+        ncfg = SimpleNamespace(network='mlp', observation_dim=[1, 1, 27], n_actions=A, n_stacked_observations=1,
+                               encoding_size=int(rng.choice([8, 24, 40])), fc_reward_layers=[fc], fc_policy_layers=[fc],
+                               fc_value_layers=[fc], fc_representation_layers=[fc], fc_hidden_state_layers=[2 * fc],
+                               support_limit=L, blocks=0)
     net0 = MuZeroNetwork(ncfg, seed=1000 * SEED + trial)
     sd = {k: v.clone() for k, v in net0.state_dict().items()}
     scale = float(rng.choice([0.0, 1e-6, 1e-3, 1.0, 1.0, 10.0, 100.0]))     # flat ... peaked policy heads
@@ -56,15 +71,15 @@ for trial in range(TRIALS):
         sd[k] *= scale
     net = MuZeroNetwork(ncfg, sd).to('cuda')
     pm_io = pack_network_mfma(net)
-    cfg = make_config(True, 9, S, players, gamma)
+    cfg = make_config(True, A, S, players, gamma)
     obs = rng.uniform(-1, 1, size=(B, 27)).astype(np.float32)
     with torch.no_grad():
         logits, hidden, value = net.initial_flat(torch.as_tensor(obs, device='cuda'))
-    legal = np.ones((B, 9))
+    legal = np.ones((B, A))
     for b in range(0, B, 3):
-        legal[b, rng.choice(9, size=rng.integers(1, 8), replace=False)] = 0
+        legal[b, rng.choice(A, size=rng.integers(1, A), replace=False)] = 0
     tp = rng.integers(0, players, size=B).astype(np.int32)
-    g = rng.gumbel(size=(B, 9))
+    g = rng.gumbel(size=(B, A))
     want = run(False, 32, cfg, net, pm_io, logits, hidden, value, legal, tp, g, B)
     ok = True
     for tm in (32, 16):
@@ -81,7 +96,7 @@ for trial in range(TRIALS):
                 if not np.array_equal(tw[k], tg[k], equal_nan=True):
                     ok = False; print(f'trial {trial} tm={tm}: tree field {k} differs')
     bad += not ok
-    print(f'trial {trial}: S={S} B={B} players={players} L={L} blocks={ncfg.blocks} policy scale {scale:g} '
+    print(f'trial {trial}: A={A} rows={"32" if os.environ.get("MZ_IDX16") else "auto"} {"board" if board else "mlp"} S={S} B={B} players={players} L={L} blocks={ncfg.blocks} policy scale {scale:g} '
           f'mean visits per simulation {want["nv"].mean() / max(S, 1):.1f}  {"ok" if ok else "MISMATCH"}', flush=True)
 print(f'{TRIALS - bad} of {TRIALS} configurations bit-identical')
 sys.exit(1 if bad else 0)

@@ -1,7 +1,10 @@
 """GPU: the Gumbel whole-search kernel that walks cached decisions (csrc/search_cached.h) against the kernel that
 scores every node on the way down (k_search_mfma).  Both evaluate leaves with the same matrix-core code, so every
 tree field must agree bit for bit - fresh searches, searches resumed after stepped simulations, illegal root
-actions, either player to move, ragged batches, both tile sizes."""
+actions, either player to move, ragged batches, both tile sizes, 2 to 16 actions, records with 16- and 32-bit
+visit / index rows."""
+from types import SimpleNamespace
+
 import numpy as np
 import pytest
 import torch
@@ -134,6 +137,52 @@ def test_decisions_without_a_certified_lead(mode, monkeypatch):
     want = _run(monkeypatch, False, 32, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
     if mode == 'deep':
         assert want['nv'].max() > S * S // 3     # leaf depth grows with every simulation
+    for tm in (32, 16):
+        got = _run(monkeypatch, True, tm, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
+        for k in ('action', 'value', 'probs', 'q', 'nv'):
+            np.testing.assert_array_equal(want[k], got[k], err_msg=f'{k} tm={tm}')
+        for tw, tg in zip(want['trees'], got['trees']):
+            for k in tw:
+                np.testing.assert_array_equal(tw[k], tg[k], err_msg=f'{k} tm={tm}')
+
+
+def _mlp(A, seed):
+    shape = SimpleNamespace(network='mlp', observation_dim=[1, 1, 12], n_actions=A, n_stacked_observations=1,
+                            encoding_size=24, fc_reward_layers=[16], fc_policy_layers=[16], fc_value_layers=[16],
+                            fc_representation_layers=[16], fc_hidden_state_layers=[32], support_limit=10)
+    net = MuZeroNetwork(shape, seed=seed)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    for k in [k for k in sd if 'policy' in k and (k.endswith('weight') or k.endswith('bias'))][-2:]:
+        sd[k] *= 8.0                               # priors with leaders: trees with some depth
+    return MuZeroNetwork(shape, sd).to('cuda')
+
+
+@pytest.mark.parametrize('A,rows', [(2, None), (3, None), (4, None), (5, None), (8, None), (12, None), (16, None),
+                                    (4, 32), (9, 32), (16, 32)])
+def test_cached_decisions_for_other_action_counts_and_row_widths(A, rows, monkeypatch):
+    """The kernel is built for every action count a 16-lane group serves and for both widths of the visit / index rows
+    (mz_create narrows them to 16 bits only where that shortens the record; MZ_IDX16=0 keeps 32 bits everywhere).
+    MZ_SEARCH_CACHED=2 makes the engine refuse any other kernel."""
+    from muzero_amd.packing import pack_network_mfma
+    if rows == 32:
+        monkeypatch.setenv('MZ_IDX16', '0')
+    else:
+        monkeypatch.delenv('MZ_IDX16', raising=False)
+    net = _mlp(A, seed=A)
+    pm_io = pack_network_mfma(net)
+    rng = np.random.default_rng(100 + A)
+    B, S = 77, 64
+    cfg = make_config(True, A, S, 2, 0.997)
+    obs = rng.standard_normal((B, 12)).astype(np.float32)
+    with torch.no_grad():
+        logits, hidden, value = net.initial_flat(torch.as_tensor(obs, device='cuda'))
+    legal = np.ones((B, A))
+    for b in range(0, B, 3):
+        legal[b, rng.choice(A, size=rng.integers(1, A), replace=False)] = 0
+    tp = rng.integers(0, 2, size=B).astype(np.int32)
+    g = rng.gumbel(size=(B, A))
+    want = _run(monkeypatch, False, 32, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
+    assert want['nv'].sum() > B * S * 2
     for tm in (32, 16):
         got = _run(monkeypatch, True, tm, cfg, net, pm_io, logits, hidden, value, legal, tp, g, 0, B)
         for k in ('action', 'value', 'probs', 'q', 'nv'):
