@@ -290,10 +290,19 @@ typedef struct mz_env_state {
     int32_t *to_play;           /* [B] game.to_play() for the next search (in/out) */
     uint8_t *legal;             /* [B][A] game.legal_actions() for the next search (in/out) */
     float *cur_obs;             /* [B][obs] current observation (in/out) */
-    float *search_obs;          /* [B][obs] observation the next search starts from (in/out) */
+    float *search_obs;          /* [B][n_stacked_observations * (1 + stack_action)][obs] what the next search starts
+                                   from (in/out): one observation, or the stack described below */
     int32_t *moves;             /* [B] moves played in the current game (in/out) */
     const double *reset_state;  /* CartPole: f64[B][4] initial states, uniform(-0.05, 0.05), consumed when an
                                    environment restarts; TicTacToe: NULL */
+    int32_t n_stacked_observations; /* config.n_stacked_observations; 0 counts as 1 */
+    int32_t stack_action;       /* config.stack_action: 1 = every observation of the stack is followed by a plane
+                                   filled with action / n_actions.  With more than one observation or with action
+                                   planes, search_obs is GameHistory.stack_n_observations(-1, ...) of the game so far
+                                   (games/game.py:120-160, called at self_play.py:86-91): newest saved observation
+                                   first, zero planes where the game is younger than the stack, and for a game that
+                                   has not started the initial observation followed by zero planes.  That rule is the
+                                   stale one by construction, so stale_observation must be 1. */
 } mz_env_state;
 
 /* Replaces one iteration of SelfPlay.play's loop after the search (self_play.py:99-113) for every

@@ -1628,8 +1628,15 @@ static int act_env_step(mz_ctx *c, const mz_env_state *env, const mz_move_log *l
         lg = LogDev{log->observations, log->actions, log->to_plays, log->rewards, log->root_values, log->probs, log->done,
                     (long long)row * log->n_envs};
     }
+    const int n_stack = env->n_stacked_observations > 0 ? env->n_stacked_observations : 1;
+    if (n_stack > 1024 || (env->stack_action != 0 && env->stack_action != 1))
+        return fail(MZ_ERR_ARG, f + ": n_stacked_observations / stack_action out of range");
+    if ((n_stack > 1 || env->stack_action) && !env->stale_observation)
+        return fail(MZ_ERR_ARG, f + ": stacked observations follow the history saved so far (GameHistory.stack_n_observations), "
+                                    "which is the stale rule: set stale_observation");
     EnvDev e;
     e.kind = env->kind; e.max_moves = env->max_moves; e.stale = env->stale_observation; e.obs_size = env->obs_size;
+    e.n_stack = n_stack; e.planes = env->stack_action ? 2 : 1;
     e.state = env->state; e.mover = env->mover; e.to_play = env->to_play; e.legal = env->legal;
     e.cur_obs = env->cur_obs; e.search_obs = env->search_obs; e.moves = env->moves; e.reset_state = env->reset_state;
     MZ_LAUNCH(c, k_act_env, true, c->B, 0, stream, c->d, e, lg, temperature, u, out_action, out_probs, out_root_value,

@@ -10,6 +10,7 @@ namespace mz {
 // games.  Environment state is caller-owned device memory (mz_env_state in the header).
 struct EnvDev {
     int kind, max_moves, stale, obs_size;
+    int n_stack, planes;   // observations in the search stack, planes per observation (2 with action planes)
     void *state;
     int32_t *mover, *to_play;
     uint8_t *legal;
@@ -76,6 +77,15 @@ __device__ __forceinline__ bool cartpole_step(double *s, int action)
     return x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr;
 }
 
+// After the step: a finished game's successor starts from its first observation (followed by zero planes in a stack);
+// without the stale rule every search starts from the current observation.
+__device__ __forceinline__ void restart_or_refresh(const EnvDev &e, bool done, bool stacked, int SW, int OS, const float *cur,
+                                                   float *srch)
+{
+    if (done || (!stacked && !e.stale)) for (int i = 0; i < OS; i++) srch[i] = cur[i];
+    if (done && stacked) for (int j = OS; j < SW; j++) srch[j] = 0.0f;
+}
+
 template <int LANES, int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, LogDev lg, double temperature, const double *u,
                                                        int32_t *out_action, double *out_probs,
@@ -98,7 +108,9 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, LogDev lg
     if (out_action) out_action[t] = action;
     if (out_root_value) out_root_value[t] = rv;
     if (out_to_play) out_to_play[t] = e.to_play[t];
-    float *cur = e.cur_obs + (long long)t * OS, *srch = e.search_obs + (long long)t * OS;
+    const bool stacked = e.n_stack > 1 || e.planes > 1;
+    const int slot = e.planes * OS, SW = e.n_stack * slot;   // floats per stacked observation (+ action plane), per stack
+    float *cur = e.cur_obs + (long long)t * OS, *srch = e.search_obs + (long long)t * SW;
     uint8_t *legal = e.legal + (long long)t * A;
     if (out_obs_before) for (int i = 0; i < OS; i++) out_obs_before[(long long)t * OS + i] = cur[i];
     if (lg.actions) {
@@ -106,7 +118,20 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, LogDev lg
         lg.actions[lr] = action; lg.to_plays[lr] = e.to_play[t]; lg.root_values[lr] = rv;
     }
     // the reference searches the NEXT move from the observation saved with this one (self_play.py:86-91,108)
-    if (e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
+    if (stacked) {
+        // GameHistory.stack_n_observations(-1, ...) after this move's save (games/game.py:143-158): the saved observation
+        // and its action plane in front, the older entries one slot further back; before the first save the stack held
+        // the initial observation in front (games/game.py:134-141), which is this very observation and not an older one
+        const bool first = e.moves[t] == 0;
+        for (int j = SW - 1; j >= slot; j--) srch[j] = first ? 0.0f : srch[j - slot];
+        for (int i = 0; i < OS; i++) srch[i] = cur[i];
+        if (e.planes > 1) {
+            const float av = (float)((double)action / (double)A);
+            for (int i = 0; i < OS; i++) srch[OS + i] = av;
+        }
+    } else if (e.stale) {
+        for (int i = 0; i < OS; i++) srch[i] = cur[i];
+    }
     float reward;
     bool term;
     if (e.kind == 1) {
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, LogDev lg
         e.mover[t] = mover; e.moves[t] = moves;
         e.to_play[t] = mover == -1 ? 0 : 1;
         tictactoe_observe(b, mover, cur, legal);
-        if (done || !e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
+        restart_or_refresh(e, done, stacked, SW, OS, cur, srch);
         if (out_done) out_done[t] = done;
         if (lg.done) lg.done[lr] = done;
     } else {
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_act_env(Dev d, EnvDev e, LogDev lg
         }
         e.moves[t] = moves;
         for (int i = 0; i < 4; i++) cur[i] = (float)s[i];
-        if (done || !e.stale) for (int i = 0; i < OS; i++) srch[i] = cur[i];
+        restart_or_refresh(e, done, stacked, SW, OS, cur, srch);
         if (out_done) out_done[t] = done;
         if (lg.done) lg.done[lr] = done;
     }

@@ -44,7 +44,7 @@ class MzEnvState(C.Structure):
     _fields_ = [('kind', C.c_int32), ('max_moves', C.c_int32), ('stale_observation', C.c_int32),
                 ('obs_size', C.c_int32), ('state', C.c_void_p), ('mover', C.c_void_p), ('to_play', C.c_void_p),
                 ('legal', C.c_void_p), ('cur_obs', C.c_void_p), ('search_obs', C.c_void_p), ('moves', C.c_void_p),
-                ('reset_state', C.c_void_p)]
+                ('reset_state', C.c_void_p), ('n_stacked_observations', C.c_int32), ('stack_action', C.c_int32)]
 
 
 class MzMoveLog(C.Structure):

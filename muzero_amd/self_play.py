@@ -24,8 +24,14 @@ from .targets import MoveLog, TrajectoryStore
 class DeviceEnvs:
     """Caller-owned device state of B environments (mz_env_state of the C ABI)."""
 
-    def __init__(self, kind: str, B: int, device, max_moves: int, stale_observation: bool = True, seed: int = 0):
+    def __init__(self, kind: str, B: int, device, max_moves: int, stale_observation: bool = True, seed: int = 0,
+                 n_stacked_observations: int = 1, stack_action: bool = False):
+        """n_stacked_observations / stack_action (config fields of the same names): the search input becomes
+        GameHistory.stack_n_observations(-1, ...) of every game so far (games/game.py:120-160), kept on the device."""
         self.kind, self.B, self.device = kind, int(B), device
+        self.n_stack, self.planes = max(1, int(n_stacked_observations)), 2 if stack_action else 1
+        if (self.n_stack > 1 or stack_action) and not stale_observation:
+            raise ValueError('stacked observations follow the saved history (the stale rule): stale_observation must be on')
         self.rng = np.random.default_rng(seed)
         if kind == 'tictactoe':
             self.A, self.obs_size, self.code = 9, 27, _engine.ENV_TICTACTOE
@@ -46,13 +52,16 @@ class DeviceEnvs:
         else:
             raise ValueError(f'unknown environment {kind!r}')
         self.cur_obs = obs.contiguous()
-        self.search_obs = obs.clone()
+        # a game that has not started: the first observation followed by zero planes (games/game.py:134-141)
+        self.search_obs = torch.zeros((B, self.n_stack * self.planes * self.obs_size), dtype=torch.float32, device=device)
+        self.search_obs[:, :self.obs_size] = obs
         self.to_play = torch.zeros(B, dtype=torch.int32, device=device)
         self.moves = torch.zeros(B, dtype=torch.int32, device=device)
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         self.struct = _engine.MzEnvState(self.code, int(max_moves), int(bool(stale_observation)), self.obs_size,
                                          p(self.state), p(self.mover), p(self.to_play), p(self.legal),
-                                         p(self.cur_obs), p(self.search_obs), p(self.moves), p(self.reset_state))
+                                         p(self.cur_obs), p(self.search_obs), p(self.moves), p(self.reset_state),
+                                         self.n_stack, self.planes - 1)
 
     NOISE_BLOCK = 16   # moves whose random inputs are drawn by one set of launches
 
@@ -82,7 +91,12 @@ class BatchedSelfPlay:
                  tree_id0: int = 0, device=None, noise_mode=_engine.NOISE_COUNTER):
         self.config, self.network, self.B = config, network, int(B)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
-        self.envs = DeviceEnvs(game, B, self.device, config.max_moves, stale_observation, seed)
+        self.envs = DeviceEnvs(game, B, self.device, config.max_moves, stale_observation, seed,
+                               int(getattr(config, 'n_stacked_observations', 1) or 1), bool(getattr(config, 'stack_action', False)))
+        stack = self.envs.n_stack * self.envs.planes * self.envs.obs_size
+        if getattr(network, 'obs_size', stack) != stack:
+            raise ValueError(f'the network reads {network.obs_size} floats per observation, the environments stack '
+                             f'{self.envs.n_stack} x {self.envs.planes} planes of {self.envs.obs_size}')
         A = self.envs.A
         self.gumbel = bool(config.gumbel)
         self.tree_id0 = tree_id0

@@ -313,6 +313,17 @@ def stack_observations(observations, actions, t, n, n_actions, stack_action):
     return out
 
 
+def stack_before_move(initial_observation, observations, actions, n, n_actions, stack_action):
+    """What self-play hands to the search before a move (self_play.py:86-91): stack_n_observations(-1, ...) on the
+    history so far.  An empty history gives the initial observation followed by zero planes (games/game.py:134-141)."""
+    if len(observations) == 0:
+        first = np.asarray(initial_observation, np.float64).reshape(-1)
+        out = np.zeros((n * (2 if stack_action else 1), first.size))
+        out[0] = first
+        return out
+    return stack_observations(observations, actions, -1, n, n_actions, stack_action)
+
+
 def scalar_to_support(x, support_limit):
     """utils/network_utils.scalar_to_support on a float32 array -> (..., 2L+1) float32."""
     xf = np.ascontiguousarray(x, np.float32)

@@ -673,6 +673,35 @@ def gen_targets():
     print('targets.npz', ci, 'cases')
 
 
+def gen_stacking():
+    """GameHistory.stack_n_observations (games/game.py:120-160) for more than one stacked observation, with and
+    without action planes: what self-play hands to the search before every move (self_play.py:86-91: t = -1 on the
+    history so far, the empty history included) and what the replay buffer stacks for a sampled position."""
+    rng = np.random.default_rng(23)
+    out, ci = {}, 0
+    for A, shape, T in ((9, (3, 3, 3), 9), (2, (1, 1, 4), 12), (4, (2, 2, 3), 5)):
+        h = GameHistory(lambda a, A=A: np.eye(A)[a][None], rng.normal(size=shape))
+        obs = [h.initial_observation] + [rng.normal(size=shape) for _ in range(T)]
+        acts = [int(rng.integers(A)) for _ in range(T)]
+        p = f'c{ci}_'
+        out[p + 'observations'] = np.array(obs[:T], dtype=np.float64)   # observations[t] is saved with move t
+        out[p + 'actions'] = np.array(acts, dtype=np.int64)
+        out[p + 'meta'] = np.array([A, T], dtype=np.int64)
+        for n, stack_action in ((1, True), (2, False), (3, True), (4, False), (6, True)):
+            q = f'{p}n{n}a{int(stack_action)}_'
+            g = GameHistory(h.action_encoder, h.initial_observation)
+            before = [g.stack_n_observations(-1, n, A, stack_action)]     # before move 0: the empty history
+            for t in range(T):
+                g.save(obs[t], acts[t], 0.0, 0, [1.0 / A] * A, 0.0)
+                before.append(g.stack_n_observations(-1, n, A, stack_action))
+            out[q + 'before_move'] = np.array(before, dtype=np.float64)   # [T + 1]: entry t = the search input of move t
+            out[q + 'at'] = np.array([g.stack_n_observations(t, n, A, stack_action) for t in range(T)], dtype=np.float64)
+        ci += 1
+    out['n_cases'] = np.int64(ci)
+    np.savez_compressed(os.path.join(HERE, 'stacking.npz'), **out)
+    print('stacking.npz', ci, 'cases')
+
+
 def gen_nan_regime():
     """Searches in which the reference's own scores are NaN: with logits spread over +-64 and most actions
     illegal, the masked root priors (shifted by the maximum over ALL logits, mcts/mcts.py + utils/game_utils.py:71-78)
@@ -773,6 +802,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         gen_trainer()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'stacking':
+        gen_stacking()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'nan':
         gen_nan_regime()
         sys.exit(0)
@@ -787,6 +819,7 @@ if __name__ == '__main__':
     gen_reanalyse()
     gen_targets()
     gen_trainer()
+    gen_stacking()
     gen_nan_regime()
     gen_misc()
     gen_hash_fixtures()

@@ -80,6 +80,30 @@ def test_stacking_with_action_planes_matches_host_mirror():
             np.testing.assert_array_equal(got.reshape(want.shape), want)
 
 
+def test_stacking_matches_the_reference_fixture():
+    """tests/golden/stacking.npz: the reference's GameHistory.stack_n_observations for 1..6 stacked observations with
+    and without action planes - at every position of a game (replay buffer) and on the history so far before every
+    move, the empty history included (self-play).  The checker and the host GameHistory must both reproduce it."""
+    z = np.load(os.path.join(GOLD, 'stacking.npz'))
+    for ci in range(int(z['n_cases'])):
+        p = f'c{ci}_'
+        A, T = (int(x) for x in z[p + 'meta'])
+        obs, acts = z[p + 'observations'], z[p + 'actions']
+        d = dict(observations=obs, actions=acts, rewards=np.zeros(T), to_plays=np.zeros(T, np.int64),
+                 probs=np.full((T, A), 1.0 / A), root_values=np.zeros(T))
+        h = history_of(d, A)
+        for n, sa in ((1, True), (2, False), (3, True), (4, False), (6, True)):
+            q = f'{p}n{n}a{int(sa)}_'
+            at, before = z[q + 'at'], z[q + 'before_move']
+            for t in range(T):
+                got = orc.stack_observations(obs, acts, t, n, A, sa)
+                np.testing.assert_array_equal(got.reshape(at[t].shape), at[t])
+                np.testing.assert_array_equal(h.stack_n_observations(t, n, A, sa), at[t])
+            for t in range(T + 1):
+                got = orc.stack_before_move(obs[0], obs[:t], acts[:t], n, A, sa)
+                np.testing.assert_array_equal(got.reshape(before[t].shape), before[t])
+
+
 def test_scalar_to_support_matches_reference():
     z = np.load(os.path.join(GOLD, 'targets.npz'))
     for ci in range(int(z['n_cases'])):
