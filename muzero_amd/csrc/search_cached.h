@@ -516,8 +516,10 @@ __global__ __launch_bounds__(TM * 16, 2) void k_search_gcache(Dev d, MfmaNet net
         MZ_MSTAMP(st_c)
         MZ_XSTART()
         if (live) {
+            // value and reward first: the backup needs them, and its record stores then travel while the new hidden
+            // state is scaled and stored (below); the re-decision phase waits for the records, not for the state
             double value, reward;
-            tile_epilogue(net, row, a, hid + (long long)leaf * H, &value, &reward);
+            support_to_scalar2<16>(row + net.io[5], row + net.io[3], net.io[9], a, &value, &reward);
             const float lg = on ? row[net.io[4] + a] : 0.0f;
 #ifdef MZ_STAMPS
             if (value == 12345.678 && lg == 7.0f) st_a++;
@@ -543,6 +545,7 @@ __global__ __launch_bounds__(TM * 16, 2) void k_search_gcache(Dev d, MfmaNet net
                     else item_list[atomicAdd(&s_total, 1)] = item_word(i, leaf);
                 }
             }
+            tile_hidden_out<16>(net, row, a, hid + (long long)leaf * H);
 #ifdef MZ_STAMPS
             MZ_XSTAMP(2)
 #endif
