@@ -43,6 +43,7 @@ struct Dev {
     uint32_t *noise_calls;  // [B] PUCT selection calls so far in this search
     long long *visit_total; // [B] sum over simulations of (depth + 1)
     int32_t *path;          // [B][S] (node << 6 | action) per level of the last descent
+    int32_t *dec;           // [B][N] cached PUCT decisions of the level-by-level search (tree_ops.h puct_decide), or NULL
     const int32_t *cv_table;  // [(A + 1)][S] sequential-halving schedules per considered count
     const double *c_table;    // [S + 2]
     const double *sqrt_table; // [(S + 2)][S + 1] sqrt(n / (1 + c)) for small S (PUCT), else NULL

@@ -259,6 +259,7 @@ extern "C" mz_ctx *mz_create(const mz_config *cfg)
     rc |= dev_alloc(c, &d.noise_calls, B);
     rc |= dev_alloc(c, &d.visit_total, B);
     rc |= dev_alloc(c, &d.path, B * S);
+    if (!cfg->gumbel) rc |= dev_alloc(c, &d.dec, B * L.N);
     rc |= dev_alloc(c, &d.err, (size_t)1);
     rc |= dev_alloc(c, &c->node_tmp, (size_t)MZ_MAX_ACTIONS);
     rc |= dev_alloc(c, &c->node_act, (size_t)1);
@@ -495,6 +496,12 @@ static int lvl_issue_range(mz_ctx *c, int n_sims, const double *noise, int32_t n
     const int tile0 = (int)((long long)tiles * r / n_ranges), tile1 = (int)((long long)tiles * (r + 1) / n_ranges);
     const int t_first = tile0 * 32, t_end = std::min(tile1 * 32, c->B);
     const int first_leaf = c->n_expanded + 1;
+    // PUCT: decisions that no tie-break draw can change are kept in a table and re-made only for the nodes a simulation
+    // touched (tree_ops.h puct_decide).  The table describes nothing yet: other calls may have changed the trees.
+    bool cached = !c->cfg.gumbel && c->d.dec != nullptr;
+    if (const char *e = getenv("MZ_PUCT_CACHE")) cached = cached && atoi(e) != 0;
+    if (cached)
+        HIPCHK(hipMemsetAsync(c->d.dec + (size_t)t_first * c->d.L.N, 0, (size_t)(t_end - t_first) * c->d.L.N * 4, rs));
     for (int s = 0; s < n_sims; s++) {
         for (int l = 0; l < net.n_levels; l++) {
             const int j0 = c->mnet_level_job0[l], nb = c->mnet_level_job0[l + 1] - j0;
@@ -503,7 +510,7 @@ static int lvl_issue_range(mz_ctx *c, int n_sims, const double *noise, int32_t n
                                          desc + MZ_LVL_DESC * j0, acts, t_first, l));
         }
         if (!launch_leaf_backup_select(c->rl, c->cfg.gumbel != 0, rs, c->d, net, t_first, t_end, first_leaf + s, acts, noise,
-                                       (int)noise_max_calls, s + 1 < n_sims))
+                                       (int)noise_max_calls, (s + 1 < n_sims ? 1 : 0) | (cached ? 2 : 0)))
             return fail(MZ_ERR_ARG, "mz_search_run: unsupported action count");
     }
     return launch_status("mz_search_run");

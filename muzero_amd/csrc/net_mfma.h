@@ -683,8 +683,9 @@ __device__ __forceinline__ void leaf_epilogue_regs(const MfmaNet &net, LeafRegs<
 
 // Tree side of one simulation for trees [t_first, t_end), one wave per tree: the epilogue of the leaf evaluation that
 // the level kernels left in `acts` (hidden-state scaling, supports to scalars), expansion + backup, and - unless this
-// was the last simulation - the next simulation's selection, whose network inputs go straight into the tree's row of
-// `acts` for the next level launch.
+// was the last simulation (select_next bit 0) - the next simulation's selection, whose network inputs go straight into
+// the tree's row of `acts` for the next level launch.  select_next bit 1 (PUCT): descend over cached decisions
+// (tree_ops.h puct_decide); the table must have been cleared when the search began.
 template <int RL, bool GUMBEL>
 __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet net, int t_first, int t_end, int leaf,
                                                                   float *acts, const double *noise, int noise_max_calls,
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     MZ_SSTAMP(slot_, 1)
     expand_backup<64, GUMBEL>(d, m, a, on, parent, action, ntp, depth, leaf, lg, value, reward, s_bk + (threadIdx.x / 64) * 64);
     if (a == 0) d.visit_total[t] += depth + 1;
-    if (!select_next) {
+    if (!(select_next & 1)) {
         if (a == 0) d.sel_depth[t] = -1;
         return;
     }
@@ -743,7 +744,27 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-    parent = descend<64, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+    bool cached = false;
+    if constexpr (!GUMBEL) cached = (select_next & 2) != 0 && d.dec != nullptr;
+    if (cached) {
+        if constexpr (!GUMBEL) {
+            // the records this simulation changed - the path and the new leaf - get their decisions again, one lane per
+            // node or per group of lanes; everything else in the table still stands
+            int32_t *dec = d.dec + (long long)t * d.L.N;
+            const int n_path = depth < d.L.S ? depth : d.L.S;
+            auto node_of = [&](int j) { return j < n_path ? m.path[j] >> 6 : leaf; };
+            const int n = n_path + 1;
+            if (n <= 4) puct_decide_list<16>(d, dc, m, dec, n, a, node_of);
+            else if (n <= 8) puct_decide_list<8>(d, dc, m, dec, n, a, node_of);
+            else if (n <= 16) puct_decide_list<4>(d, dc, m, dec, n, a, node_of);
+            else if (n <= 32) puct_decide_list<2>(d, dc, m, dec, n, a, node_of);
+            else puct_decide_list<1>(d, dc, m, dec, n, a, node_of);
+            __threadfence_block();
+            parent = descend_cached_puct<RL>(d, dc, m, dec, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+        }
+    } else {
+        parent = descend<64, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+    }
     MZ_SSTAMP(slot_, 3)
     if (a == 0) {
         if constexpr (!GUMBEL) store_noise_calls(d, t, calls, noise_max_calls);

@@ -254,6 +254,139 @@ __device__ __forceinline__ int descend(const Dev &d, const DescendCtx &c, const 
     return node;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cached PUCT decisions.  The action muzero_action_selection picks at a node (mcts/action_selection.py:25-49 with
+// mcts/qtransforms.py:7-22) is the argmax of u + q + 1e-7 * uniform[0, 1): u and q are functions of the node's own
+// record, which only changes when the node lies on a simulation's path, and the tie-break term is below 1e-7.  Where
+// the best u + q leads the runner-up by more than that, no draw can change the choice: the decision is kept in a table
+// (word = (children_index[node, action] + 1) << 8 | action) and the next descents read it instead of scoring the node.
+// Nodes without such a lead keep the word 0 and are scored in full, with the call's draws, whenever a descent meets
+// them.  A descent still counts one selection call per level, so the noise stream stays where the reference's is.
+//
+// One LANE evaluates one node, looping over the actions.  The scores are evaluated cheaply (reciprocals refined by
+// Newton steps instead of divisions and a square root): they differ from the reference's by a few units in the last
+// place of the score (1e-15 relative), which the lead demanded, 1e-7 plus a millionth of that per unit of score, covers.
+// NaN or infinite scores are never certified.
+__device__ __forceinline__ double rcp_refined(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+
+// G lanes share a node (lane g of the group takes actions g, g + G, ...): short paths are decided by wide groups, long
+// ones by many narrow groups at once.  Every lane of the wave must call it (the group reductions move data across
+// lanes); all lanes of a group return the node's word.
+template <int G>
+__device__ __forceinline__ int puct_decide(const Dev &d, const DescendCtx &c, const TreeMem &m, int node, int g)
+{
+    const RowView w = view(d, m, node);
+    const int A = d.L.A, nv = w.hdr->visits;
+    const double nval = w.hdr->value, inf = __builtin_huge_val();
+    const double *prior = reinterpret_cast<const double *>(w.prior);
+    double lo = nval, hi = nval;
+    int bad = nval != nval;
+    for (int a = g; a < A; a += G) {
+        const double q = w.crew[a] + d.discount * w.cval[a];
+        const double safe = w.cvis.get(a) > 0 ? q : nval;
+        bad |= safe != safe;
+        lo = safe < lo ? safe : lo;
+        hi = safe > hi ? safe : hi;
+    }
+    lo = gmin<G>(lo); hi = gmax<G>(hi);
+    double den = hi - lo;
+    den = den < 1e-8 ? 1e-8 : den;
+    const double rden = rcp_refined(den);
+    const double cc = c.c_table_lds ? c.c_table_lds[nv] : c.c_table[nv];
+    const double nvd = (double)nv;
+    double b1 = -inf, b2 = -inf;
+    int best = 0x7fffffff;
+    for (int a = g; a < A; a += G) {
+        if (node == 0 && !((c.legal >> a) & 1ull)) continue;   // masked_argmax at the root: illegal actions never win
+        const int cv = w.cvis.get(a);
+        const double q = w.crew[a] + d.discount * w.cval[a];
+        const double nq = ((cv > 0 ? q : lo) - lo) * rden;
+        // sqrt(N / (1 + n_a)) = x * rsqrt(x), the reciprocal square root refined twice
+        const double x = nvd * rcp_refined((double)(1 + cv));
+        double r = __builtin_amdgcn_rsq(x);
+        r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+        r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+        const double sq = nv > 0 ? x * r : 0.0;
+        const double sc = (cc * prior[a] + sq) + nq;
+        bad |= sc != sc;
+        if (sc > b1) { b2 = b1; b1 = sc; best = a; }
+        else if (sc > b2) b2 = sc;
+    }
+    // the group's best and runner-up: the runner-up is the largest of the other lanes' bests and the winner's own second;
+    // two lanes with the same best are a tie (no lead)
+    const double gb1 = gmax<G>(b1);
+    const bool mine = b1 == gb1;
+    const int winners = gsumi<G>(mine ? 1 : 0);
+    double gb2 = gmax<G>(mine ? b2 : b1);
+    gb2 = winners > 1 ? gb1 : gb2;
+    const int gbest = -gmaxi<G>(mine ? -best : -0x7fffffff);
+    bad = gsumi<G>(bad);
+    const bool sure = !bad && gb1 > -1e300 && gb1 < 1e300 && (gb1 - gb2) > 1.000001e-7 + 1e-13 * __builtin_fabs(gb1);
+    return sure ? ((w.cidx.get(gbest) + 1) << 8) | gbest : 0;
+}
+
+// The decisions of nodes [0, n) of a list (`node_of(j)` names the j-th) into `dec`, by the whole wave.
+template <int G, typename F>
+__device__ __forceinline__ void puct_decide_list(const Dev &d, const DescendCtx &c, const TreeMem &m, int32_t *dec, int n,
+                                                 int lane, F node_of)
+{
+    constexpr int PER = 64 / G;   // nodes per pass
+    for (int j0 = 0; j0 < n; j0 += PER) {   // wave-uniform trip count
+        const int j = j0 + lane / G;
+        const bool has = j < n;
+        const int node = has ? node_of(j) : 0;
+        const int word = puct_decide<G>(d, c, m, node, lane % G);
+        if (has && lane % G == 0) dec[node] = word;
+    }
+}
+
+// descend() over the decision table of a whole-wave group: a table hit costs one 4-byte load per level; a miss is scored
+// by the RL action lanes exactly as descend() does.  Every lane takes part; results are wave-uniform.
+template <int RL>
+__device__ __forceinline__ int descend_cached_puct(const Dev &d, const DescendCtx &c, const TreeMem &m, const int32_t *dec,
+                                                   int a, bool on, const double *noise, int noise_max_calls, uint32_t &calls,
+                                                   int *action_out, int *ntp_out, int *depth_out)
+{
+    int node = 0, depth = 0, ntp = 0, action = 0;
+    while (true) {
+        // (volatile: the table is written by this kernel, the load must not go through the scalar cache)
+        const int word = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int32_t *>(dec + node));
+        int child;
+        if (word != 0) {
+            action = word & 0xff;
+            child = (word >> 8) - 1;
+        } else {
+            int packed = 0;
+            if (a < RL) {
+                double u = 0.0;
+                if (on) {
+                    if (d.noise_mode == 0) u = noise_from_key(c.key, calls, (unsigned)a);
+                    else if (d.noise_mode == 1 && (int)calls < noise_max_calls) u = noise[(long long)calls * d.L.A + a];
+                }
+                int ch;
+                const int act = select_at<RL, false>(d, c, m, node, depth, a, on, u, &ch);
+                packed = ((ch + 1) << 8) | act;
+            }
+            packed = __builtin_amdgcn_readfirstlane(packed);
+            action = packed & 0xff;
+            child = (packed >> 8) - 1;
+        }
+        calls++;
+        if (a == 0 && depth < d.L.S) m.path[depth] = (node << 6) | action;
+        ntp = d.players == 1 ? ntp : 1 - ntp;
+        depth++;
+        if (child < 0 || depth > d.L.S) break;
+        node = child;
+    }
+    *action_out = action; *ntp_out = ntp; *depth_out = depth;
+    return node;
+}
+
 // The same descent for a whole-wave group over a tree of at most 2 * (64 / RL) nodes whose records sit
 // in LDS: every live node's selection is evaluated at once (RL lanes per node; the decision at a node is
 // a pure function of its statistics and of the tie-break noise of call `calls + depth(node)`), then the
