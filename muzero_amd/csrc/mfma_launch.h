@@ -47,6 +47,7 @@ bool search_gcache_supported(const Dev &d, const MfmaNet &net, int tm);
 hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const MfmaNet &net, int first_leaf, int n_sims);
 // Level by level through global memory: k_stage_inputs, k_net_level_rows (one level for a range of 32-tree tiles),
 // and for whole searches k_leaf_backup_select.
+#define MZ_DEC_LDS 256  // nodes of a tree whose cached PUCT decisions k_leaf_backup_select keeps in LDS (larger trees: in memory)
 #define MZ_LVL_DESC 40  // ints per block descriptor of k_net_level_rows: KK, in_off, N, out_off, skip_off, act, bias_off,
                         // n column tiles, first column tile, dense flag, then per wave: weight byte offset, blocks, kidx offset
 static_assert(MZ_LVL_DESC >= 10 + 3 * MZ_LVL_WAVES, "a block descriptor holds three ints per wave after its ten header ints");

@@ -694,6 +694,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     __shared__ __align__(16) double s_bk[MZ_BLOCK];
     __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
     __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
+    __shared__ int32_t s_dec[GUMBEL ? 1 : MZ_BLOCK / 64][GUMBEL ? 1 : MZ_DEC_LDS];   // the waves' decision tables
     const int t = t_first + (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / 64), a = threadIdx.x % 64;
     const bool on = a < d.L.A;
     // the pending selection is asked for before the tables are staged: both waits overlap
@@ -705,10 +706,25 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     const bool wide = net.io[9] > 64 && net.io[9] <= 640 && net.io[10] == 1 && H > 16 && H <= 256 && !net.plane_major;
     LeafRegs<10, 4> lr;
     float lg = 0.0f;
+    // cached PUCT decisions: the tree's table travels to the wave while the epilogue and the backup run (a walk that
+    // reads it from memory level by level waits for HBM at every level: the level kernels in between flush the L2)
+    bool cached = false, dec_in_lds = false;
+    int dec_pre[MZ_DEC_LDS / 64];
+    if constexpr (!GUMBEL) {
+        cached = (select_next & 3) == 3 && d.dec != nullptr;
+        dec_in_lds = cached && d.L.N <= MZ_DEC_LDS;
+    }
     if (live) {
         parent = d.sel_parent[t]; action = d.sel_action[t]; ntp = d.sel_ntp[t]; depth = d.sel_depth[t];
         lg = on ? row[net.io[4] + a] : 0.0f;
         if (wide) leaf_epilogue_load<10, 4>(net, row, a, lr);
+        if constexpr (!GUMBEL) {
+            if (dec_in_lds) {
+                const int32_t *dec = d.dec + (long long)t * d.L.N;
+#pragma unroll
+                for (int k = 0; k < MZ_DEC_LDS / 64; k++) dec_pre[k] = a + 64 * k < d.L.N ? dec[a + 64 * k] : 0;
+            }
+        }
     }
 
 #ifdef MZ_STAMPS
@@ -717,6 +733,19 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
 #endif
     const double *ct = stage_c_table<GUMBEL>(d, s_ct);
     const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
+    // searches too long for the sqrt(n / (1 + c)) table: its two factors, sqrt(n) and 1 / sqrt(1 + c), for the cached
+    // decisions (their product is within two units in the last place of the quotient's root)
+    bool sq_factors = false;
+    if constexpr (!GUMBEL) {
+        sq_factors = (select_next & 3) == 3 && d.dec != nullptr && sqt == nullptr && 2 * (d.L.S + 2) <= MZ_SQ_LDS;
+        if (sq_factors) {
+            for (int i = threadIdx.x; i < d.L.S + 2; i += MZ_BLOCK) {
+                s_sq[i] = sqrt((double)i);
+                s_sq[d.L.S + 2 + i] = 1.0 / sqrt((double)(1 + i));
+            }
+            __syncthreads();
+        }
+    }
     if (t >= t_end) return;
     MZ_SSTAMP(slot_, 0)
     if (depth < 1 || depth > d.L.S || parent < 0 || parent >= leaf) {
@@ -743,24 +772,49 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     MZ_SSTAMP(slot_, 2)
     const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
+    if (sq_factors) { dc.sqrt_n = s_sq; dc.rsqrt_1c = s_sq + d.L.S + 2; }
     uint32_t calls = GUMBEL ? 0u : d.noise_calls[t];
-    bool cached = false;
-    if constexpr (!GUMBEL) cached = (select_next & 2) != 0 && d.dec != nullptr;
     if (cached) {
         if constexpr (!GUMBEL) {
             // the records this simulation changed - the path and the new leaf - get their decisions again, one lane per
             // node or per group of lanes; everything else in the table still stands
             int32_t *dec = d.dec + (long long)t * d.L.N;
+            int32_t *dec_lds = dec_in_lds ? s_dec[threadIdx.x / 64] : nullptr;
+            if (dec_in_lds) {
+#pragma unroll
+                for (int k = 0; k < MZ_DEC_LDS / 64; k++) dec_lds[a + 64 * k] = dec_pre[k];
+                lds_fence();
+            }
             const int n_path = depth < d.L.S ? depth : d.L.S;
             auto node_of = [&](int j) { return j < n_path ? m.path[j] >> 6 : leaf; };
             const int n = n_path + 1;
-            if (n <= 4) puct_decide_list<16>(d, dc, m, dec, n, a, node_of);
-            else if (n <= 8) puct_decide_list<8>(d, dc, m, dec, n, a, node_of);
-            else if (n <= 16) puct_decide_list<4>(d, dc, m, dec, n, a, node_of);
-            else if (n <= 32) puct_decide_list<2>(d, dc, m, dec, n, a, node_of);
-            else puct_decide_list<1>(d, dc, m, dec, n, a, node_of);
-            __threadfence_block();
-            parent = descend_cached_puct<RL>(d, dc, m, dec, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
+            // lanes per node: as many as cover the list in one pass, but no fewer than keep a lane's share of the
+            // actions in registers (then a pass waits for memory once; longer lists take several passes)
+            const int A = d.L.A;
+            const int g_regs = A <= MZ_PUCT_NA ? 1 : A <= 2 * MZ_PUCT_NA ? 2 : A <= 4 * MZ_PUCT_NA ? 4 : 8;
+            const int g_list = n <= 4 ? 16 : n <= 8 ? 8 : n <= 16 ? 4 : n <= 32 ? 2 : 1;
+            const int G = g_list > g_regs ? g_list : g_regs;
+            if (G == 16) puct_decide_list<16>(d, dc, m, dec, dec_lds, n, a, node_of);
+            else if (G == 8) puct_decide_list<8>(d, dc, m, dec, dec_lds, n, a, node_of);
+            else if (G == 4) puct_decide_list<4>(d, dc, m, dec, dec_lds, n, a, node_of);
+            else if (G == 2) puct_decide_list<2>(d, dc, m, dec, dec_lds, n, a, node_of);
+            else puct_decide_list<1>(d, dc, m, dec, dec_lds, n, a, node_of);
+            // the walk below reads the LDS copy; the table in memory is for the next launch
+            if (dec_in_lds) lds_fence();
+            else __threadfence_block();
+            int misses_ = 0;
+#ifdef MZ_STAMPS
+            const long long t_dec_ = clock64();
+#endif
+            if (dec_in_lds)
+                parent = descend_cached_puct<RL, true>(d, dc, m, dec, dec_lds, a, on, nz, noise_max_calls, calls, &action, &ntp,
+                                                       &depth, &misses_);
+            else
+                parent = descend_cached_puct<RL, false>(d, dc, m, dec, dec_lds, a, on, nz, noise_max_calls, calls, &action, &ntp,
+                                                        &depth, &misses_);
+#ifdef MZ_STAMPS
+            if (slot_ >= 0) { mz_dbg_stamps[slot_ * 8 + 6] = misses_; mz_dbg_stamps[slot_ * 8 + 7] = clock64() - t_dec_; }
+#endif
         }
     } else {
         parent = descend<64, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);

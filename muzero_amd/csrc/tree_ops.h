@@ -152,6 +152,8 @@ struct DescendCtx {
     const double *c_table;        // exploration constants in global memory
     const double *c_table_lds;    // LDS copy of the whole table when the kernel staged one, else NULL
     const double *sq_table;       // sqrt(n / (1 + c)) table in LDS, or NULL
+    const double *sqrt_n;         // [S + 2] sqrt(n) and
+    const double *rsqrt_1c;       // [S + 2] 1 / sqrt(1 + c) in LDS for the cached PUCT decisions, or NULL
     const int32_t *cv_row;        // sequential-halving schedule of this tree's considered count
     double gumbel_a;              // this lane's Gumbel noise
 };
@@ -162,6 +164,7 @@ __device__ __forceinline__ DescendCtx descend_ctx(const Dev &d, int t, int a, bo
 {
     DescendCtx c;
     c.sq_table = sq_table_lds;
+    c.sqrt_n = c.rsqrt_1c = nullptr;
     c.legal = d.legal[t];
     c.key = GUMBEL ? 0ull : noise_key(d.seed, d.tree_id0 + (unsigned long long)t);
     c.c_table = d.c_table;
@@ -277,21 +280,40 @@ __device__ __forceinline__ double rcp_refined(double x)
 // G lanes share a node (lane g of the group takes actions g, g + G, ...): short paths are decided by wide groups, long
 // ones by many narrow groups at once.  Every lane of the wave must call it (the group reductions move data across
 // lanes); all lanes of a group return the node's word.
+#define MZ_PUCT_NA 8   // actions per lane that puct_decide_regs keeps in registers
 template <int G>
 __device__ __forceinline__ int puct_decide(const Dev &d, const DescendCtx &c, const TreeMem &m, int node, int g)
 {
+    constexpr int UB = 4;   // actions per lane whose loads are issued together (a loop over single actions pays the
+                            // memory latency once per action)
     const RowView w = view(d, m, node);
     const int A = d.L.A, nv = w.hdr->visits;
     const double nval = w.hdr->value, inf = __builtin_huge_val();
     const double *prior = reinterpret_cast<const double *>(w.prior);
+    // an entry of the visit / index rows without a branch on their width: the aligned 32-bit word that holds it
+    const bool i16 = w.cvis.i16;
+    auto row_get = [&](const char *p, int a) {
+        const int word = *reinterpret_cast<const int32_t *>(p + (i16 ? (2 * a) & ~3 : 4 * a));
+        return i16 ? (int)(int16_t)(word >> ((a & 1) * 16)) : word;
+    };
     double lo = nval, hi = nval;
     int bad = nval != nval;
-    for (int a = g; a < A; a += G) {
-        const double q = w.crew[a] + d.discount * w.cval[a];
-        const double safe = w.cvis.get(a) > 0 ? q : nval;
-        bad |= safe != safe;
-        lo = safe < lo ? safe : lo;
-        hi = safe > hi ? safe : hi;
+    for (int a0 = g; a0 < A; a0 += UB * G) {
+        double q[UB];
+        int cv[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const int a = a0 + k * G < A ? a0 + k * G : g;   // past the end: the lane's first action again (harmless here)
+            cv[k] = row_get(w.cvis.p, a);
+            q[k] = w.crew[a] + d.discount * w.cval[a];
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const double safe = cv[k] > 0 ? q[k] : nval;
+            bad |= safe != safe;
+            lo = safe < lo ? safe : lo;
+            hi = safe > hi ? safe : hi;
+        }
     }
     lo = gmin<G>(lo); hi = gmax<G>(hi);
     double den = hi - lo;
@@ -301,21 +323,33 @@ __device__ __forceinline__ int puct_decide(const Dev &d, const DescendCtx &c, co
     const double nvd = (double)nv;
     double b1 = -inf, b2 = -inf;
     int best = 0x7fffffff;
-    for (int a = g; a < A; a += G) {
-        if (node == 0 && !((c.legal >> a) & 1ull)) continue;   // masked_argmax at the root: illegal actions never win
-        const int cv = w.cvis.get(a);
-        const double q = w.crew[a] + d.discount * w.cval[a];
-        const double nq = ((cv > 0 ? q : lo) - lo) * rden;
-        // sqrt(N / (1 + n_a)) = x * rsqrt(x), the reciprocal square root refined twice
-        const double x = nvd * rcp_refined((double)(1 + cv));
-        double r = __builtin_amdgcn_rsq(x);
-        r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
-        r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
-        const double sq = nv > 0 ? x * r : 0.0;
-        const double sc = (cc * prior[a] + sq) + nq;
-        bad |= sc != sc;
-        if (sc > b1) { b2 = b1; b1 = sc; best = a; }
-        else if (sc > b2) b2 = sc;
+    for (int a0 = g; a0 < A; a0 += UB * G) {
+        double q[UB], pr[UB];
+        int cv[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const int a = a0 + k * G < A ? a0 + k * G : g;
+            cv[k] = row_get(w.cvis.p, a);
+            q[k] = w.crew[a] + d.discount * w.cval[a];
+            pr[k] = prior[a];
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const int a = a0 + k * G;
+            // masked_argmax at the root: illegal actions never win
+            if (a >= A || (node == 0 && !((c.legal >> a) & 1ull))) continue;
+            const double nq = ((cv[k] > 0 ? q[k] : lo) - lo) * rden;
+            // sqrt(N / (1 + n_a)) = x * rsqrt(x), the reciprocal square root refined twice
+            const double x = nvd * rcp_refined((double)(1 + cv[k]));
+            double r = __builtin_amdgcn_rsq(x);
+            r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+            r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+            const double sq = nv > 0 ? x * r : 0.0;
+            const double sc = (cc * pr[k] + sq) + nq;
+            bad |= sc != sc;
+            if (sc > b1) { b2 = b1; b1 = sc; best = a; }
+            else if (sc > b2) b2 = sc;
+        }
     }
     // the group's best and runner-up: the runner-up is the largest of the other lanes' bests and the winner's own second;
     // two lanes with the same best are a tie (no lead)
@@ -327,40 +361,169 @@ __device__ __forceinline__ int puct_decide(const Dev &d, const DescendCtx &c, co
     const int gbest = -gmaxi<G>(mine ? -best : -0x7fffffff);
     bad = gsumi<G>(bad);
     const bool sure = !bad && gb1 > -1e300 && gb1 < 1e300 && (gb1 - gb2) > 1.000001e-7 + 1e-13 * __builtin_fabs(gb1);
-    return sure ? ((w.cidx.get(gbest) + 1) << 8) | gbest : 0;
+    const int gsafe = gbest < A ? gbest : 0;
+    return sure ? ((row_get(w.cidx.p, gsafe) + 1) << 8) | gbest : 0;
 }
 
-// The decisions of nodes [0, n) of a list (`node_of(j)` names the j-th) into `dec`, by the whole wave.
-template <int G, typename F>
-__device__ __forceinline__ void puct_decide_list(const Dev &d, const DescendCtx &c, const TreeMem &m, int32_t *dec, int n,
-                                                 int lane, F node_of)
+// The same decision when a lane's share of the actions fits in registers (at most NA per lane): every value the node
+// needs - the child indices included - is asked for at once (puct_load), so a lane waits for memory once per node
+// instead of once per batch and pass and once more for the winner's child; the caller asks for the next node's values
+// before it evaluates this one's (puct_decide_regs).
+template <int NA>
+struct PuctRegs {
+    double q[NA], pr[NA], nval;
+    int cv[NA], ci[NA], nv;
+};
+
+template <int G, int NA>
+__device__ __forceinline__ void puct_load(const Dev &d, const TreeMem &m, int node, int g, PuctRegs<NA> &r)
 {
-    constexpr int PER = 64 / G;   // nodes per pass
-    for (int j0 = 0; j0 < n; j0 += PER) {   // wave-uniform trip count
-        const int j = j0 + lane / G;
-        const bool has = j < n;
-        const int node = has ? node_of(j) : 0;
-        const int word = puct_decide<G>(d, c, m, node, lane % G);
-        if (has && lane % G == 0) dec[node] = word;
+    const RowView w = view(d, m, node);
+    const int A = d.L.A;
+    const double *prior = reinterpret_cast<const double *>(w.prior);
+    const bool i16 = w.cvis.i16;
+    auto row_get = [&](const char *p, int a) {   // an entry of the visit / index rows without a branch on their width
+        const int word = *reinterpret_cast<const int32_t *>(p + (i16 ? (2 * a) & ~3 : 4 * a));
+        return i16 ? (int)(int16_t)(word >> ((a & 1) * 16)) : word;
+    };
+    r.nv = w.hdr->visits;
+    r.nval = w.hdr->value;
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+        const int a = g + k * G < A ? g + k * G : g;   // past the end: the lane's first action again (never scored)
+        r.cv[k] = row_get(w.cvis.p, a);
+        r.ci[k] = row_get(w.cidx.p, a);
+        r.q[k] = w.crew[a] + d.discount * w.cval[a];
+        r.pr[k] = prior[a];
     }
 }
 
-// descend() over the decision table of a whole-wave group: a table hit costs one 4-byte load per level; a miss is scored
-// by the RL action lanes exactly as descend() does.  Every lane takes part; results are wave-uniform.
-template <int RL>
-__device__ __forceinline__ int descend_cached_puct(const Dev &d, const DescendCtx &c, const TreeMem &m, const int32_t *dec,
-                                                   int a, bool on, const double *noise, int noise_max_calls, uint32_t &calls,
-                                                   int *action_out, int *ntp_out, int *depth_out)
+template <int G, int NA>
+__device__ __forceinline__ int puct_decide_regs(const Dev &d, const DescendCtx &c, int node, int g, const PuctRegs<NA> &r)
 {
-    int node = 0, depth = 0, ntp = 0, action = 0;
+    const int A = d.L.A, nv = r.nv;
+    const double nval = r.nval, inf = __builtin_huge_val();
+    const double cc = c.c_table_lds ? c.c_table_lds[nv] : c.c_table[nv];
+    double lo = nval, hi = nval;
+    int bad = nval != nval;
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+        const double safe = r.cv[k] > 0 ? r.q[k] : nval;
+        bad |= safe != safe;
+        lo = safe < lo ? safe : lo;
+        hi = safe > hi ? safe : hi;
+    }
+    lo = gmin<G>(lo); hi = gmax<G>(hi);
+    double den = hi - lo;
+    den = den < 1e-8 ? 1e-8 : den;
+    const double rden = rcp_refined(den);
+    const double nvd = (double)nv, sqn = c.sqrt_n ? c.sqrt_n[nv] : 0.0;
+    double b1 = -inf, b2 = -inf;
+    int best = 0x7fffffff, best_ci = -1;
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+        const int a = g + k * G;
+        if (a >= A || (node == 0 && !((c.legal >> a) & 1ull))) continue;   // masked_argmax at the root
+        const double nq = ((r.cv[k] > 0 ? r.q[k] : lo) - lo) * rden;
+        double sq;   // sqrt(N / (1 + n_a)) to a few units in the last place
+        if (c.sqrt_n) {
+            sq = sqn * c.rsqrt_1c[r.cv[k]];
+        } else {
+            const double x = nvd * rcp_refined((double)(1 + r.cv[k]));
+            double rs = __builtin_amdgcn_rsq(x);
+            rs = rs * __builtin_fma(-0.5 * x * rs, rs, 1.5);
+            rs = rs * __builtin_fma(-0.5 * x * rs, rs, 1.5);
+            sq = nv > 0 ? x * rs : 0.0;
+        }
+        const double sc = (cc * r.pr[k] + sq) + nq;
+        bad |= sc != sc;
+        if (sc > b1) { b2 = b1; b1 = sc; best = a; best_ci = r.ci[k]; }
+        else if (sc > b2) b2 = sc;
+    }
+    const double gb1 = gmax<G>(b1);
+    const bool mine = b1 == gb1;
+    const int winners = gsumi<G>(mine ? 1 : 0);
+    const double gb2 = gmax<G>(mine ? b2 : b1);
+    const int gbest = -gmaxi<G>(mine ? -best : -0x7fffffff);
+    const int gchild1 = gmaxi<G>(mine ? best_ci + 1 : 0);   // children_index + 1 of the winner (one winner: see `sure`)
+    bad = gsumi<G>(bad);
+    const bool sure = !bad && winners == 1 && gb1 > -1e300 && gb1 < 1e300 &&
+                      (gb1 - gb2) > 1.000001e-7 + 1e-13 * __builtin_fabs(gb1);
+    return sure ? (gchild1 << 8) | gbest : 0;
+}
+
+// The decisions of nodes [0, n) of a list (`node_of(j)` names the j-th) into `dec` and, when the wave keeps a copy of
+// its tree's table in LDS, into that copy (`dec_lds`, else NULL), by the whole wave.
+template <int G, typename F>
+__device__ __forceinline__ void puct_decide_list(const Dev &d, const DescendCtx &c, const TreeMem &m, int32_t *dec,
+                                                 int32_t *dec_lds, int n, int lane, F node_of)
+{
+    constexpr int PER = 64 / G;   // nodes per pass
+    const int g = lane % G;
+    auto put = [&](bool has, int node, int word) {
+        if (has && g == 0) {
+            dec[node] = word;
+            if (dec_lds) dec_lds[node] = word;
+        }
+    };
+    const int per_lane = (d.L.A + G - 1) / G;
+    auto pipelined = [&](auto na) {
+        constexpr int NA = decltype(na)::value;
+        PuctRegs<NA> cur, nxt;
+        int j = lane / G;
+        bool has = j < n;
+        int node = has ? node_of(j) : 0;
+        puct_load<G>(d, m, node, g, cur);
+        for (int j0 = 0; j0 < n; j0 += PER) {   // wave-uniform trip count
+            const int jn = j + PER;
+            const bool has_n = jn < n;
+            const int node_n = has_n ? node_of(jn) : 0;
+            if (j0 + PER < n) puct_load<G>(d, m, node_n, g, nxt);   // on its way while this pass is evaluated
+            put(has, node, puct_decide_regs<G>(d, c, node, g, cur));
+            cur = nxt; j = jn; has = has_n; node = node_n;
+        }
+    };
+    if (per_lane <= 4) {
+        pipelined(std::integral_constant<int, 4>());
+    } else if (per_lane <= 6) {
+        pipelined(std::integral_constant<int, 6>());
+    } else if (per_lane <= MZ_PUCT_NA) {
+        pipelined(std::integral_constant<int, MZ_PUCT_NA>());
+    } else {
+        for (int j0 = 0; j0 < n; j0 += PER) {
+            const int j = j0 + lane / G;
+            const bool has = j < n;
+            const int node = has ? node_of(j) : 0;
+            put(has, node, puct_decide<G>(d, c, m, node, g));
+        }
+    }
+}
+
+// descend() over the decision table of a whole-wave group: a table hit costs one 4-byte read per level - from the wave's
+// LDS copy of the table (`dec_lds`) when it has one, else from memory, where every level of the walk waits for a trip
+// to HBM; a miss is scored by the RL action lanes exactly as descend() does.  Every lane takes part; results are
+// wave-uniform.
+// The path goes to memory 64 levels at a time (lane k keeps level k of the current stretch): a store per level would make
+// every level wait for the one before it, since the wait for a table word from memory also covers the stores in flight.
+template <int RL, bool IN_LDS>
+__device__ __forceinline__ int descend_cached_puct(const Dev &d, const DescendCtx &c, const TreeMem &m, const int32_t *dec,
+                                                   const int32_t *dec_lds, int a, bool on, const double *noise,
+                                                   int noise_max_calls, uint32_t &calls, int *action_out, int *ntp_out,
+                                                   int *depth_out, int *misses = nullptr)
+{
+    int node = 0, depth = 0, ntp = 0, action = 0, path_reg = 0;
     while (true) {
-        // (volatile: the table is written by this kernel, the load must not go through the scalar cache)
-        const int word = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int32_t *>(dec + node));
+        // (LDS reads and atomic loads of workgroup scope: the compiler neither moves them into the scalar cache, which
+        // does not see this kernel's stores, nor sends them past the L2 as it does volatile ones)
+        int word;
+        if constexpr (IN_LDS) word = __builtin_amdgcn_readfirstlane(dec_lds[node]);
+        else word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(dec + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         int child;
         if (word != 0) {
             action = word & 0xff;
             child = (word >> 8) - 1;
         } else {
+            if (misses) *misses += 1;
             int packed = 0;
             if (a < RL) {
                 double u = 0.0;
@@ -377,12 +540,14 @@ __device__ __forceinline__ int descend_cached_puct(const Dev &d, const DescendCt
             child = (packed >> 8) - 1;
         }
         calls++;
-        if (a == 0 && depth < d.L.S) m.path[depth] = (node << 6) | action;
+        path_reg = a == (depth & 63) ? (node << 6) | action : path_reg;
         ntp = d.players == 1 ? ntp : 1 - ntp;
         depth++;
+        if ((depth & 63) == 0 && depth - 64 + a < d.L.S) m.path[depth - 64 + a] = path_reg;   // a full stretch
         if (child < 0 || depth > d.L.S) break;
         node = child;
     }
+    if ((depth & 63) != 0 && a < (depth & 63) && (depth & ~63) + a < d.L.S) m.path[(depth & ~63) + a] = path_reg;
     *action_out = action; *ntp_out = ntp; *depth_out = depth;
     return node;
 }

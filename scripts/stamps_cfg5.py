@@ -39,4 +39,5 @@ tr = ['selection + tables', 'epilogue', 'expansion + backup', 'descent', 'inputs
 x = buf[512:768]
 print('k_leaf_backup_select (last simulation but one), cycles per block: ' +
       '  '.join('%s %.0f/%.0f' % (n, v, w) for n, v, w in zip(tr, x[:, :5].mean(0), x[:, :5].max(0))) +
-      '  depth of the new selection %.2f' % x[:, 5].mean())
+      '  depth of the new selection %.2f' % x[:, 5].mean() +
+      '  (cached decisions: levels scored in full %.2f per descent, walk %.0f/%.0f cycles)' % (x[:, 6].mean(), x[:, 7].mean(), x[:, 7].max()))
