@@ -174,6 +174,9 @@ def main():
     if os.environ.get('MZ_BENCH_SIMS'):    # experiments only: another simulation count
         S = int(os.environ['MZ_BENCH_SIMS'])
         desc += f' [experiment: {S} simulations]'
+    for switch in ('MZ_PUCT_CACHE', 'MZ_SEARCH_CHAIN', 'MZ_SEARCH_CACHED', 'MZ_SEARCH_TM', 'MZ_IDX16'):
+        if os.environ.get(switch) is not None:   # kernel-selection switches of the library: the line names them
+            desc += f' [experiment: {switch}={os.environ[switch]}]'
     leaf_macs = None
     root_on_device = False
     cfg = search_config(gumbel, A, S, players, gamma)
@@ -459,7 +462,9 @@ LIMITER = {
             'HBM (measured traffic 2.0 TB/s) nor the matrix pipes (20% busy) saturate',
     'mfma_levels': 'a chain of three launches per simulation over only 1024 trees: every launch is bound by its own start-up, '
                    'memory round trips and drain (matrix instructions are 3.3 of a level launch\'s 13.7 us), and the chain '
-                   'is serial by construction (the next selection needs this backup)',
+                   'is serial by construction (the next selection needs this backup); the tree launch lasts as long as its '
+                   'deepest tree (one wave per tree: epilogue, backup, re-decision of the path nodes by lane groups, a walk '
+                   'down the cached PUCT decisions)',
 }
 
 

@@ -402,6 +402,11 @@ int mz_considered_visits(int32_t max_considered_actions, int32_t simulations, in
 int mz_legacy_root_noise(uint32_t *mt_key, int32_t *mt_pos, double alpha, int32_t n_actions, int32_t B,
                          int32_t with_uniform, double *out_dirichlet, double *out_u);
 
+/* np.random.gumbel(size=n) of the same legacy generator - the draw of gumbel_noise in MCTS.search (mcts/mcts.py:211),
+ * for n = B * n_actions the draws of B consecutive searches: out f64[n] = -log(-log(1 - next_double())) in stream
+ * order; state in and out as for mz_legacy_root_noise.  Host only; the logarithms run on a few host threads. */
+int mz_legacy_gumbel(uint32_t *mt_key, int32_t *mt_pos, int64_t n, double *out);
+
 /* Library/ABI version. */
 int mz_version(void);
 

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <thread>
 #include <vector>
 
 #include <map>
@@ -177,6 +178,29 @@ extern "C" int mz_legacy_root_noise(uint32_t *mt_key, int32_t *mt_pos, double al
         if (with_uniform) out_u[b] = mt.next_double();
     }
     *mt_pos = mt.pos;
+    return MZ_OK;
+}
+
+// np.random.gumbel(size=n) of the legacy generator (numpy/random/src/legacy/legacy-distributions.c legacy_gumbel with
+// loc 0, scale 1): u = 1 - next_double(), value = -log(-log(u)), one uniform per value in order.  The uniforms come off
+// the Mersenne Twister one after the other; the two logarithms per value - nearly all of the time - are taken by a few
+// host threads side by side, each with the C library's log on its own stretch, so every value has the bits NumPy gives.
+extern "C" int mz_legacy_gumbel(uint32_t *mt_key, int32_t *mt_pos, int64_t n, double *out)
+{
+    if (!mt_key || !mt_pos || n < 0 || (n > 0 && !out) || *mt_pos < 0 || *mt_pos > 624)
+        return fail(MZ_ERR_ARG, "mz_legacy_gumbel: bad argument");
+    LegacyMT mt{mt_key, *mt_pos};
+    for (int64_t i = 0; i < n; i++) out[i] = 1.0 - mt.next_double();
+    *mt_pos = mt.pos;
+    auto transform = [out](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) out[i] = -log(-log(out[i])); };
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t n_threads = std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), n / 8192);   // a thread per 8192 values at least
+    if (const char *e = getenv("MZ_HOST_THREADS")) n_threads = std::min<int64_t>(n_threads, std::max(1, atoi(e)));
+    if (n_threads <= 1) { transform(0, n); return MZ_OK; }
+    std::vector<std::thread> pool;
+    for (int64_t k = 1; k < n_threads; k++) pool.emplace_back(transform, n * k / n_threads, n * (k + 1) / n_threads);
+    transform(0, n / n_threads);
+    for (std::thread &t : pool) t.join();
     return MZ_OK;
 }
 

@@ -57,7 +57,7 @@ ENV_TICTACTOE, ENV_CARTPOLE = 1, 2
 
 EXPORTS = ['mz_create', 'mz_destroy', 'mz_last_error', 'mz_set_seed', 'mz_check', 'mz_root_prepare', 'mz_tree_reset', 'mz_select',
            'mz_select_outputs', 'mz_expand_backup', 'mz_to_act', 'mz_search_run', 'mz_search_run_act', 'mz_search_move', 'mz_set_network', 'mz_set_root_network', 'mz_search_begin_net', 'mz_set_network_mfma', 'mz_set_root_network_mfma', 'mz_initial_inference_mfma', 'mz_expand_backup_net', 'mz_expand_backup_net_static', 'mz_act_env_step', 'mz_act_env_step_log', 'mz_log_count_games', 'mz_log_list_games', 'mz_tree_export',
-           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_legacy_root_noise', 'mz_make_targets', 'mz_scalar_to_support',
+           'mz_stats', 'mz_node_qtransform', 'mz_node_select', 'mz_node_backward', 'mz_tree_import', 'mz_considered_visits', 'mz_legacy_root_noise', 'mz_legacy_gumbel', 'mz_make_targets', 'mz_scalar_to_support',
            'mz_version']
 
 
@@ -104,6 +104,7 @@ def lib():
         L.mz_tree_import.argtypes = [vp, i32, C.POINTER(MzTreeHost), vp, vp, vp]
         L.mz_stats.argtypes = [vp, vp, vp, vp]
         L.mz_legacy_root_noise.argtypes = [vp, vp, C.c_double, i32, i32, i32, vp, vp]
+        L.mz_legacy_gumbel.argtypes = [vp, vp, C.c_int64, vp]
         L.mz_node_qtransform.argtypes = [vp, i32, i32, i32, vp, vp]
         L.mz_node_select.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         L.mz_considered_visits.argtypes = [i32, i32, vp]
@@ -152,6 +153,24 @@ def legacy_root_noise(alpha: float, n_actions: int, B: int, with_uniform: bool):
                                       u.ctypes.data_as(C.c_void_p) if with_uniform else None), 'mz_legacy_root_noise')
     np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
     return di, u
+
+
+def legacy_gumbel(shape):
+    """np.random.gumbel(size=shape) from the GLOBAL NumPy stream in one native call (the stream is left where NumPy
+    would leave it): the uniforms come off the Mersenne Twister in order, the logarithms are taken on a few host threads.
+    For the root noise of thousands of Gumbel searches NumPy's single-threaded draw costs as much as a tenth of the
+    search itself.  Falls back to NumPy when the global generator is not MT19937 or the draw is small."""
+    n = int(np.prod(shape))
+    state = np.random.get_state()
+    if state[0] != 'MT19937' or n < 16384:
+        return np.random.gumbel(size=shape)
+    key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(state[2]))
+    out = np.empty(n, np.float64)
+    _check(lib().mz_legacy_gumbel(key.ctypes.data_as(C.c_void_p), C.byref(pos), C.c_int64(n),
+                                  out.ctypes.data_as(C.c_void_p)), 'mz_legacy_gumbel')
+    np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
+    return out.reshape(shape)
 
 
 def c_table_numpy(config) -> np.ndarray:

@@ -172,7 +172,7 @@ class MCTS:
         # search once batches reach thousands of trees.
         g = dirichlet = u_pre = None
         if gumbel:
-            g = np.random.gumbel(size=(B, A))     # row b = the b-th search's np.random.gumbel(size=A) (mcts/mcts.py:211)
+            g = _engine.legacy_gumbel((B, A))     # row b = the b-th search's np.random.gumbel(size=A) (mcts/mcts.py:211)
         elif stream_noise:
             dirichlet, _ = _engine.legacy_root_noise(float(cfg.dirichlet_alpha), A, B, with_uniform=False)
         else:

@@ -56,3 +56,34 @@ def test_gumbel_rows_are_the_consecutive_draws():
     want = np.stack([np.random.gumbel(size=9) for _ in range(1000)])
     np.random.seed(11)
     np.testing.assert_array_equal(np.random.gumbel(size=(1000, 9)), want)
+
+
+@pytest.mark.parametrize('n', [16384, 20000, 16384 * 9, 300001])
+def test_native_gumbel_draws_are_numpys(n):
+    """np.random.gumbel(size=(B, A)) of MCTS.search_batch in one native call: the values, bit for bit, and the stream
+    position afterwards (the next draws agree), from a state in the middle of a block of the generator and with a
+    cached Gaussian pending."""
+    np.random.seed(77)
+    np.random.standard_normal(3)      # leaves a cached Gaussian
+    np.random.random_sample(101)      # a position inside the 624-word block
+    state = np.random.get_state()
+    want = np.random.gumbel(size=n)
+    after = np.random.random_sample(5), np.random.standard_normal(1)
+    np.random.set_state(state)
+    got = engine.legacy_gumbel((n,))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.random.random_sample(5), after[0])
+    np.testing.assert_array_equal(np.random.standard_normal(1), after[1])
+
+
+def test_native_gumbel_small_draws_and_shapes():
+    np.random.seed(5)
+    want = np.random.gumbel(size=(7, 9))
+    np.random.seed(5)
+    np.testing.assert_array_equal(engine.legacy_gumbel((7, 9)), want)       # small: NumPy itself
+    np.random.seed(6)
+    want = np.random.gumbel(size=(4096, 9))
+    np.random.seed(6)
+    got = engine.legacy_gumbel((4096, 9))
+    assert got.shape == (4096, 9)
+    np.testing.assert_array_equal(got, want)
