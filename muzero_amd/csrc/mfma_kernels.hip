@@ -58,7 +58,7 @@ hipError_t launch_net_level_rows(unsigned n_jobs, unsigned n_row_tiles, int max_
 #ifdef MZ_STAMPS
     if (const char *e = getenv("MZ_LVL_STOP")) level |= atoi(e) << 8;
 #endif
-    hipLaunchKernelGGL(kern, dim3(n_jobs, n_row_tiles), dim3(MZ_LVL_WAVES * 64), lds, st, net, desc, acts, row_first, level);
+    hipLaunchKernelGGL(kern, dim3(n_row_tiles, n_jobs), dim3(MZ_LVL_WAVES * 64), lds, st, net, desc, acts, row_first, level);
     return hipSuccess;
 }
 

@@ -489,7 +489,7 @@ static __global__ __launch_bounds__(256) void k_root_outputs(int B, MfmaNet pred
 // ---------------------------------------------------------------------------------------------------
 // Whole searches level by level (networks too wide for a tile of trees in LDS, or more than 16 actions): per
 // simulation one launch per network level plus one tree launch, for a RANGE of trees [row_first, row_first + 32 *
-// gridDim.y) so that several ranges can run on streams of their own, one range's matrix work beside another's tree work.
+// gridDim.x) so that several ranges can run on streams of their own, one range's matrix work beside another's tree work.
 
 // One level for a range of trees, inputs already in `acts` (the tree kernel below stages them).  A wave asks for the
 // weights of its column tile first (up to MZ_LVL_KB blocks, a fixed number of buffer loads: blocks it does not have
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     level &= 0xff;
     if (stop_ == 1) return;
     long long kst_ = clock64();
-    const int lin_ = blockIdx.y * gridDim.x + blockIdx.x;
+    const int lin_ = blockIdx.x * gridDim.y + blockIdx.y;
     const int slot_ = (threadIdx.x == 0 && lin_ < 256 && level < 2) ? level * 256 + lin_ : -1;
 #endif
     constexpr int PT = MZ_LVL_WAVES * 64 / 32;  // threads that copy one tree's inputs
@@ -517,9 +517,13 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     // everything the block needs to know in one descriptor (MZ_LVL_DESC ints, see mz_set_network_mfma): one round
     // trip to memory between the launch and the first weight load (passing the descriptors inside the kernel
     // arguments instead was measured: 0.7 % on the 1024-tree search, not kept)
-    const int32_t *q = desc + MZ_LVL_DESC * blockIdx.x;
+    // grid = (tiles of 32 trees, blocks of column tiles): workgroups go to the eight XCDs in turn by their linear index,
+    // the tree tile is the fast one, so a tile's rows of `acts` are read and written through one XCD's L2 by all the
+    // column blocks that use them (the weights, needed by every tile, travel to every L2 either way)
+    const int job_ = blockIdx.y, tile_ = blockIdx.x;
+    const int32_t *q = desc + MZ_LVL_DESC * job_;
     const int KK = q[0], ts = KK + 4, in_off = q[1];
-    const int t0 = row_first + blockIdx.y * 32;
+    const int t0 = row_first + tile_ * 32;
     const bool active = wave < q[7];
     const int32_t *qw = q + 10 + 3 * (active ? wave : 0);
     const int w_off = qw[0], nkb = active ? qw[1] : 0;

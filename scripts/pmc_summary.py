@@ -7,13 +7,13 @@ from muzero_amd.build import source_fingerprint
 
 tag, rnd = sys.argv[1], sys.argv[2]
 DOMINANT = {'cfg3': 'k_search_gcache', 'cfg2': 'k_search_reg', 'cfg4s': 'k_search_reg', 'cfg3h': 'k_search_hash',
-            'cfg5': 'k_net_level_rows'}
+            'cfg5': 'k_net_level_rows', 'cfg5d': 'k_net_level_rows'}
 NOTE = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py (5 steps), mean over the '
         'kernel launches; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (counters are in KiB; gfx950 tallies 128-byte '
         'read requests at 64 bytes).  Calibrated on this access pattern with k_to_act of the same runs: 8192 root '
         'records of 128 B plus 128 KB of per-tree inputs = 1.15 MB read, FETCH_SIZE 573 KB; 360 KB written, '
         'WRITE_SIZE 352 KB')
-PER_SEARCH = {'cfg5': 'k_stage_inputs'}   # launched once per search
+PER_SEARCH = {'cfg5': 'k_stage_inputs', 'cfg5d': 'k_stage_inputs'}   # launched once per search
 traffic, raw = {}, {}
 st = glob.glob(f'gpurun_out/{tag}_stats_default/**/*kernel_stats.csv', recursive=True)
 if st:
