@@ -699,7 +699,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     __shared__ __align__(16) double s_ct[GUMBEL ? 2 : MZ_CT_LDS];
     __shared__ __align__(16) double s_sq[GUMBEL ? 2 : MZ_SQ_LDS];
     __shared__ int32_t s_dec[GUMBEL ? 1 : MZ_BLOCK / 64][GUMBEL ? 1 : MZ_DEC_LDS];   // the waves' decision tables
-    const int t = t_first + (int)((blockIdx.x * (unsigned)MZ_BLOCK + threadIdx.x) / 64), a = threadIdx.x % 64;
+    // Workgroups go to the eight XCDs in turn by their index, the level kernels keep a 32-tree tile's activation rows in
+    // the L2 of XCD (tile mod 8): the eight blocks of four trees that make up a tile are given indices that land on that
+    // XCD (within whole groups of 64 blocks, the two 3-bit fields of the index change places).
+    unsigned vb = blockIdx.x;
+    if ((vb | 63u) < gridDim.x) vb = (vb & ~63u) | ((vb & 7u) << 3) | ((vb >> 3) & 7u);
+    const int t = t_first + (int)((vb * (unsigned)MZ_BLOCK + threadIdx.x) / 64), a = threadIdx.x % 64;
     const bool on = a < d.L.A;
     // the pending selection is asked for before the tables are staged: both waits overlap
     int parent = 0, action = 0, ntp = 0, depth = 0;
