@@ -400,7 +400,7 @@ def main():
         from muzero_amd.build import source_fingerprint
         with open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')) as f:
             entry = json.load(f).get(args.workload)
-        if entry is not None and os.environ.get('MZ_BENCH_TREES') is None and os.environ.get('MZ_BENCH_SIMS') is None:
+        if entry is not None and '[experiment' not in desc:   # an experiment runs other sizes or other kernels than the entry's
             if entry.get('kernel_sources') == source_fingerprint():
                 traffic = entry.get('traffic_bytes_per_launch')
             else:

@@ -1,8 +1,8 @@
 """The measurement table of DESIGN.md, generated from a bench-lines file (one bench.py JSON line per workload) so that
 the document and the recorded lines cannot disagree.
 
-    python scripts/design_table.py profiles/round2_bench_lines.jsonl            # prints the table
-    python scripts/design_table.py profiles/round2_bench_lines.jsonl --write    # rewrites it inside DESIGN.md
+    python scripts/design_table.py profiles/round3_bench_lines.jsonl            # prints the table
+    python scripts/design_table.py profiles/round3_bench_lines.jsonl --write    # rewrites it inside DESIGN.md
 
 DESIGN.md holds the table between the markers <!-- bench-table:begin FILE --> and <!-- bench-table:end -->."""
 import json
@@ -23,7 +23,7 @@ def si(x):
 
 
 def table(path):
-    rows = ['| `--workload` | what one step is | ms/step | simulations/s | node-visits/s | dominant kernel(s) | HBM: algorithmic GB/s (frac of 8 TB/s), measured bytes / algorithmic | MFMA frac of 157.3 TF | CPU checker on the same workload |',
+    rows = ['| `--workload` | what one step is | ms/step | simulations/s | node-visits/s | dominant kernel(s) | HBM: algorithmic GB/s (frac of 8 TB/s), measured bytes / algorithmic | MFMA frac of 157.3 TF: executed flops (dense-equivalent flops) | CPU checker on the same workload |',
             '|---|---|---|---|---|---|---|---|---|']
     for line in open(path):
         line = line.strip()
@@ -39,7 +39,8 @@ def table(path):
         extra = f"; {si(d['env_steps_per_sec'])} env-steps/s" if d.get('env_steps_per_sec') else ''
         rows.append('| `%s` | %s | %.3f | %s | %s%s | %s (%.3f ms) | %s | %s | %s |' % (
             d['config']['name'], d['config']['workload'], d['ms_per_step'], si(d['value']), si(d['node_visits_per_sec']), extra,
-            r['kernel'], r['kernel_ms'], hbm, f"{mf['frac']:.3f}" if mf else '-',
+            r['kernel'], r['kernel_ms'], hbm,
+            (f"{mf['frac']:.3f}" + (f" ({mf['dense_equivalent']['frac']:.3f})" if 'dense_equivalent' in mf else '')) if mf else '-',
             f"{si(cpu['value'])} sims/s on {cpu['cores']} threads ({cpu['kind']})" if cpu else '-'))
     return '\n'.join(rows)
 
