@@ -39,8 +39,12 @@ __device__ __forceinline__ float apply_act(float v, int act)
 }
 
 // Operand layout of a (step, column tile) job.  Lane (r = lane & 15, q = lane >> 4) supplies, for the j-th of four
-// k-steps of a 16-wide k block, A[row r][k = 16*blk + 4q + j] (four consecutive floats of its tree's activations: one
-// 16-byte LDS read) and the matching weight W[col][same k] (one 16-byte global read of the pre-swizzled fragment).
+// k-steps of a 16-wide k block, X[tree r][k = 16*blk + 4q + j] (four consecutive floats of its tree's activations: one
+// 16-byte LDS read) and the matching weight W[col r][same k] (one 16-byte global read of the pre-swizzled fragment).
+// The WEIGHTS are the matrix instruction's first operand and the activations its second: the result then has output
+// columns down the registers - lane (r, q) holds columns 4q .. 4q + 3 of tree r - so a job's outputs, its residual
+// input and its biases are single 16-byte accesses per lane (with the operands the other way round a lane held one
+// column of four trees: four scattered 4-byte accesses each).
 #define MZ_WPF 10  // weight blocks fetched per round (k blocks of 16; a job with more runs in rounds of this)
 
 // ---------------------------------------------------------------------------------------------------
@@ -61,7 +65,7 @@ struct TileSched {
 
 struct WReg {
     float4 w[MZ_WPF];
-    float bias;
+    float4 bias;   // of output columns 4q .. 4q + 3 of the job's tile (q = lane >> 4)
 };
 
 typedef unsigned int u32x4 __attribute__((vector_size(16)));
@@ -115,8 +119,8 @@ __device__ __forceinline__ void tile_wload(const NetBufs &nb, const TileSched &t
         const int voff = i < nkb ? lane * 16 + i * 1024 : 0x7ffffff0;
         r.w[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, voff, w_off, 0));
     }
-    const int boff = (lane & 15) < ncols ? (lane & 15) * 4 : 0x7ffffff0;
-    r.bias = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(nb.b, boff, b_col * 4, 0));
+    const int boff = ncols > 0 ? (lane >> 4) * 16 : 0x7ffffff0;   // (the bias array is padded to whole tiles of 16)
+    r.bias = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.b, boff, b_col * 4, 0));
 }
 
 // Workgroup barrier that orders LDS traffic only: global loads in flight (the weights of a later job) stay in flight
@@ -144,14 +148,14 @@ __device__ __forceinline__ void mfma_blocks(const float *a0, const float *a1, co
             if constexpr (HALVES == 2) n1 = *reinterpret_cast<const float4 *>(a1 + kb[i + 1] * 16);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads of block i + 1 ahead of block i's matrix instructions
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, w[i].x, acc0, 0, 0, 0);
-        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w[i].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, w[i].y, acc0, 0, 0, 0);
-        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w[i].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, w[i].z, acc0, 0, 0, 0);
-        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w[i].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, w[i].w, acc0, 0, 0, 0);
-        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w[i].w, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x0.x, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x0.y, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x0.z, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x0.w, acc0, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x1.w, acc1, 0, 0, 0);
         x0 = n0; x1 = n1;
     }
 }
@@ -227,19 +231,20 @@ __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, 
             else mfma_round<1>(n, a0, a1, w, kb2, acc0, acc1);
         }
     }
-    // C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + register
-    const int c = lane & 15;
-    if (c < ncols) {
-        const float b = first.bias;
-        float *o0 = act + (row0 + (lane >> 4) * 4) * net.stride + c, *o1 = o0 + 16 * net.stride;
+    // C/D layout of 16x16x4 with the weights as first operand: tree = lane & 15, output column = (lane >> 4) * 4 + register
+    const int c0 = (lane >> 4) * 4;
+    if (c0 < ncols) {
+        const float bb[4] = {first.bias.x, first.bias.y, first.bias.z, first.bias.w};
+        float *o0 = act + (row0 + (lane & 15)) * net.stride + c0, *o1 = o0 + 16 * net.stride;
         float v0[4], v1[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { v0[j] = acc0[j] + b; v1[j] = acc1[j] + b; }
-        if (skip_col >= 0) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                v0[j] += o0[j * net.stride + skip_col];
-                if (both) v1[j] += o1[j * net.stride + skip_col];
+        for (int j = 0; j < 4; j++) { v0[j] = acc0[j] + bb[j]; v1[j] = acc1[j] + bb[j]; }
+        if (skip_col >= 0) {   // (the residual tensor is padded to whole tiles like every tensor of the row)
+            const float4 s0 = *reinterpret_cast<const float4 *>(o0 + skip_col);
+            v0[0] += s0.x; v0[1] += s0.y; v0[2] += s0.z; v0[3] += s0.w;
+            if (both) {
+                const float4 s1 = *reinterpret_cast<const float4 *>(o1 + skip_col);
+                v1[0] += s1.x; v1[1] += s1.y; v1[2] += s1.z; v1[3] += s1.w;
             }
         }
         // the activation is the job's (wave-uniform): one branch per job, so that a ReLU layer never pays for expm1
@@ -250,10 +255,17 @@ __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, 
 #pragma unroll
             for (int j = 0; j < 4; j++) { v0[j] = apply_act(v0[j], 2); if (both) v1[j] = apply_act(v1[j], 2); }
         }
+        if (c0 + 4 <= ncols) {
+            *reinterpret_cast<float4 *>(o0 + out_col) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+            if (both) *reinterpret_cast<float4 *>(o1 + out_col) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        } else {   // the tile's last, partial group of columns: the padding behind the tensor stays as it is
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            o0[j * net.stride + out_col] = v0[j];
-            if (both) o1[j * net.stride + out_col] = v1[j];
+            for (int j = 0; j < 4; j++) {
+                if (c0 + j < ncols) {
+                    o0[out_col + j] = v0[j];
+                    if (both) o1[out_col + j] = v1[j];
+                }
+            }
         }
     }
     MZ_JSTAMP(2)
@@ -551,8 +563,10 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
             kb[i] = (KB > MZ_WPF && MZ_WPF + i < nkb) ? kx[MZ_WPF + i] : 0;
         }
     }
-    const int col = (q[8] + (active ? wave : 0)) * 16 + (lane & 15), N = q[2];
-    const float bias = (active && col < N) ? net.bias[q[6] + col] : 0.0f;
+    // (result layout as in tile_job: tree = lane & 15, output columns (lane >> 4) * 4 .. + 3 down the registers)
+    const int col = (q[8] + (active ? wave : 0)) * 16 + (lane >> 4) * 4, N = q[2];
+    float4 bias4 = {0, 0, 0, 0};
+    if (active && col < N) bias4 = *reinterpret_cast<const float4 *>(net.bias + q[6] + col);   // padded to whole tiles
     MZ_SSTAMP(slot_, 0)
     {
         const int i = tid / PT, part = tid % PT;
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     __syncthreads();
     MZ_SSTAMP(slot_, 2)
 #ifdef MZ_STAMPS
-    if (stop_ == 2) { if (wa[0].x == 12345.678f && bias == 1.0f) acts[0] = 0.0f; return; }
+    if (stop_ == 2) { if (wa[0].x == 12345.678f && bias4.x == 1.0f) acts[0] = 0.0f; return; }
 #endif
     if (!active) return;
     const float *a0 = tile + (lane & 15) * ts + (lane >> 4) * 4, *a1 = a0 + 16 * ts;
@@ -592,13 +606,15 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
 #endif
     if (col < N) {
         const int out_off = q[3], skip_off = q[4], actf = q[5];
-        float *o0 = acts + (long long)(t0 + (lane >> 4) * 4) * net.stride + col, *o1 = o0 + 16 * (long long)net.stride;
+        const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+        float *o0 = acts + (long long)(t0 + (lane & 15)) * net.stride + col, *o1 = o0 + 16 * (long long)net.stride;
         float v0[4], v1[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { v0[j] = acc0[j] + bias; v1[j] = acc1[j] + bias; }
+        for (int j = 0; j < 4; j++) { v0[j] = acc0[j] + bb[j]; v1[j] = acc1[j] + bb[j]; }
         if (skip_off >= 0) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { v0[j] += o0[(long long)j * net.stride + skip_off]; v1[j] += o1[(long long)j * net.stride + skip_off]; }
+            const float4 s0 = *reinterpret_cast<const float4 *>(o0 + skip_off), s1 = *reinterpret_cast<const float4 *>(o1 + skip_off);
+            v0[0] += s0.x; v0[1] += s0.y; v0[2] += s0.z; v0[3] += s0.w;
+            v1[0] += s1.x; v1[1] += s1.y; v1[2] += s1.z; v1[3] += s1.w;
         }
         // the activation is the block's: one uniform branch, so that linear and ReLU layers never pay for expm1
         if (actf == 1) {
@@ -608,8 +624,14 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
 #pragma unroll
             for (int j = 0; j < 4; j++) { v0[j] = apply_act(v0[j], 2); v1[j] = apply_act(v1[j], 2); }
         }
+        if (col + 4 <= N) {
+            *reinterpret_cast<float4 *>(o0 + out_off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+            *reinterpret_cast<float4 *>(o1 + out_off) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        } else {   // the layer's last, partial group of columns
 #pragma unroll
-        for (int j = 0; j < 4; j++) { o0[(long long)j * net.stride + out_off] = v0[j]; o1[(long long)j * net.stride + out_off] = v1[j]; }
+            for (int j = 0; j < 4; j++)
+                if (col + j < N) { o0[out_off + j] = v0[j]; o1[out_off + j] = v1[j]; }
+        }
     }
 }
 
