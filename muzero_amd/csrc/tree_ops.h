@@ -390,7 +390,9 @@ __device__ __forceinline__ void puct_load(const Dev &d, const TreeMem &m, int no
     r.nval = w.hdr->value;
 #pragma unroll
     for (int k = 0; k < NA; k++) {
-        const int a = g + k * G < A ? g + k * G : g;   // past the end: the lane's first action again (never scored)
+        // past the end: an action that exists, again (it enters the range twice, which changes nothing, and is never
+        // scored; a lane whose first action is already past the end - groups wider than the action count - takes action 0)
+        const int a = g + k * G < A ? g + k * G : (g < A ? g : 0);
         r.cv[k] = row_get(w.cvis.p, a);
         r.ci[k] = row_get(w.cidx.p, a);
         r.q[k] = w.crew[a] + d.discount * w.cval[a];

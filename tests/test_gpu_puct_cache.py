@@ -30,8 +30,8 @@ def _search(monkeypatch, shape, peaked, B, S, cached, noise_mode='counter', step
     cfg = make_config(False, A, S, 1, 0.997)
     obs = torch.as_tensor(rng.standard_normal((B, shape.observation_dim[-1])).astype(np.float32), device='cuda')
     legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
-    legal[::4, 2] = 0
-    legal[1::7, :A - 2] = 0
+    legal[::4, min(2, A - 1)] = 0
+    legal[1::7, :max(A - 2, 1)] = 0
     di = rng.dirichlet([0.25] * A, size=B)
     with torch.no_grad():
         logits, hidden, value = gnet.initial_flat(obs)
@@ -90,6 +90,21 @@ def test_cached_puct_decisions_with_exact_ties(monkeypatch):
     ref = _search(monkeypatch, ODD, False, 64, 50, cached=False, tied=True)
     got = _search(monkeypatch, ODD, False, 64, 50, cached=True, tied=True)
     _same(got, ref)
+
+
+@pytest.mark.parametrize('A', [2, 5, 11, 16])
+def test_cached_puct_decisions_with_fewer_actions_than_lanes_per_node(A, monkeypatch):
+    """Short lists are decided by groups of up to 16 lanes per node: with fewer actions than that some lanes of a group
+    have no action at all and must not contribute to the node's value range (MZ_SEARCH_LEVELS=1 sends these small
+    action counts down the level-by-level path)."""
+    monkeypatch.setenv('MZ_SEARCH_LEVELS', '1')
+    shape = SimpleNamespace(network='mlp', observation_dim=[1, 1, 24], n_actions=A, n_stacked_observations=1,
+                            encoding_size=24, fc_reward_layers=[32], fc_policy_layers=[32], fc_value_layers=[32],
+                            fc_representation_layers=[32], fc_hidden_state_layers=[32], support_limit=10)
+    for peaked in (False, True):
+        ref = _search(monkeypatch, shape, peaked and A > 7, 90, 60, cached=False)
+        got = _search(monkeypatch, shape, peaked and A > 7, 90, 60, cached=True)
+        _same(got, ref)
 
 
 def test_cached_puct_at_the_benchmark_size(monkeypatch):
