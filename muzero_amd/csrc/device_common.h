@@ -8,8 +8,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 
 namespace mz {
+
+// Compile-time loop: f(std::integral_constant<int, 0>()), ..., f(std::integral_constant<int, N - 1>()).  Indexing
+// an array in registers needs indices that are constants, which an unrolled runtime loop does not always give.
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>(), f); }
 
 // ----------------------------------------------------------------- storage layout
 // One node = one contiguous record (64-byte aligned):

@@ -503,11 +503,11 @@ static __global__ __launch_bounds__(256) void k_root_outputs(int B, MfmaNet pred
 // simulation one launch per network level plus one tree launch, for a RANGE of trees [row_first, row_first + 32 *
 // gridDim.x) so that several ranges can run on streams of their own, one range's matrix work beside another's tree work.
 
-// One level for a range of trees, inputs already in `acts` (the tree kernel below stages them).  A wave asks for the
-// weights of its column tile first (up to MZ_LVL_KB blocks, a fixed number of buffer loads: blocks it does not have
-// are addressed out of range and cost no memory access; wider layers fetch the rest in rounds later), then the block
-// copies its trees' input columns into LDS, so the weights' latency hides behind the copy's.  Same k order per output
-// as tile_job.
+// One level for a range of trees, inputs already in `acts` (the tree kernel below stages them).  A thread asks for its
+// share of the trees' input columns, then its wave for the weights of its column tile (up to MZ_LVL_KB blocks, a fixed
+// number of buffer loads: blocks it does not have are addressed out of range and cost no memory access; wider layers
+// fetch the rest in rounds later); the inputs go through LDS, and the weight blocks arrive while they do and while the
+// first blocks multiply.  Same k order per output as tile_job.
 template <int KB>
 __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet net, const int32_t *desc, float *acts,
                                                                       int row_first, int level)
@@ -534,14 +534,57 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     // column blocks that use them (the weights, needed by every tile, travel to every L2 either way)
     const int job_ = blockIdx.y, tile_ = blockIdx.x;
     const int32_t *q = desc + MZ_LVL_DESC * job_;
+    // (every field is read here, before the kernel's first store: behind a store through a generic pointer the compiler
+    // no longer takes these wave-uniform reads for scalar loads, and a vector load's wait covers the weights in flight)
     const int KK = q[0], ts = KK + 4, in_off = q[1];
+    const int q_n = q[2], q_out = q[3], q_skip = q[4], q_act = q[5], q_bias = q[6], q_ct0 = q[8], q_dense = q[9];
     const int t0 = row_first + tile_ * 32;
     const bool active = wave < q[7];
     const int32_t *qw = q + 10 + 3 * (active ? wave : 0);
-    const int w_off = qw[0], nkb = active ? qw[1] : 0;
-    const NetBufs nb = net_bufs(net);
-    float4 wa[MZ_WPF], wb[MZ_WPF];
+    const int w_off = qw[0], nkb = active ? qw[1] : 0, kx_off = qw[2];
     int ka[MZ_WPF], kb[MZ_WPF];
+    if (q_dense) {   // every column tile of the block multiplies input blocks 0, 1, 2, ...: no index list to fetch
+#pragma unroll
+        for (int i = 0; i < MZ_WPF; i++) { ka[i] = i; kb[i] = MZ_WPF + i; }
+    } else {
+        const int32_t *kx = net.kidx + kx_off;
+#pragma unroll
+        for (int i = 0; i < MZ_WPF; i++) {
+            ka[i] = i < nkb ? kx[i] : 0;
+            kb[i] = (KB > MZ_WPF && MZ_WPF + i < nkb) ? kx[MZ_WPF + i] : 0;
+        }
+    }
+    const NetBufs nb = net_bufs(net);
+    // The trees' inputs are asked for FIRST and the weights behind them: loads come back in the order they were issued,
+    // and every wave needs the whole input tile (through LDS, behind the barrier) before its first matrix instruction,
+    // but its weight blocks only one after the other - so the weights stream in while the inputs are parked in LDS and
+    // while the first blocks multiply.  (Issued the other way round, the copy waited for all the weights.)  A thread's
+    // loads leave together, indices past the end of the row clamped: NB_IN of them cover layers of up to 384 inputs.
+    constexpr int NB_IN = (96 + PT - 1) / PT;
+    const int part_ = tid % PT, n4 = KK / 4;
+    const f32x4 *src4 = reinterpret_cast<const f32x4 *>(acts + (long long)(t0 + tid / PT) * net.stride + in_off);
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(tile + (tid / PT) * ts);
+    // (wider layers: the rest of a row goes first, round by round - with loads of unknown number in flight the compiler
+    // would make the first matrix instruction wait for every load, the weights included)
+    for (int j0 = part_ + NB_IN * PT; j0 < n4; j0 += NB_IN * PT) {
+        f32x4 v[NB_IN];
+        static_for<NB_IN>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            v[u] = src4[j0 + u * PT < n4 ? j0 + u * PT : n4 - 1];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NB_IN>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if (j0 + u * PT < n4) d4[j0 + u * PT] = v[u];
+        });
+    }
+    f32x4 vin[NB_IN];   // (a native vector type: arrays of it become registers; rows past the batch exist in `acts`, zero)
+    static_for<NB_IN>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        vin[u] = src4[part_ + u * PT < n4 ? part_ + u * PT : n4 - 1];
+    });
+    __builtin_amdgcn_sched_barrier(0);   // (the compiler would move these loads down to their stores, behind the weights)
+    float4 wa[MZ_WPF], wb[MZ_WPF];
 #pragma unroll
     for (int i = 0; i < MZ_WPF; i++)
         wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, i < nkb ? lane * 16 + i * 1024 : 0x7ffffff0, w_off, 0));
@@ -552,27 +595,16 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
             wb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, k < nkb ? lane * 16 + k * 1024 : 0x7ffffff0, w_off, 0));
         }
     }
-    if (q[9]) {   // every column tile of the block multiplies input blocks 0, 1, 2, ...: no index list to fetch
-#pragma unroll
-        for (int i = 0; i < MZ_WPF; i++) { ka[i] = i; kb[i] = MZ_WPF + i; }
-    } else {
-        const int32_t *kx = net.kidx + qw[2];
-#pragma unroll
-        for (int i = 0; i < MZ_WPF; i++) {
-            ka[i] = i < nkb ? kx[i] : 0;
-            kb[i] = (KB > MZ_WPF && MZ_WPF + i < nkb) ? kx[MZ_WPF + i] : 0;
-        }
-    }
     // (result layout as in tile_job: tree = lane & 15, output columns (lane >> 4) * 4 .. + 3 down the registers)
-    const int col = (q[8] + (active ? wave : 0)) * 16 + (lane >> 4) * 4, N = q[2];
+    const int col = (q_ct0 + (active ? wave : 0)) * 16 + (lane >> 4) * 4, N = q_n;
     float4 bias4 = {0, 0, 0, 0};
-    if (active && col < N) bias4 = *reinterpret_cast<const float4 *>(net.bias + q[6] + col);   // padded to whole tiles
+    if (active && col < N) bias4 = *reinterpret_cast<const float4 *>(net.bias + q_bias + col);   // padded to whole tiles
     MZ_SSTAMP(slot_, 0)
-    {
-        const int i = tid / PT, part = tid % PT;
-        const float4 *src = reinterpret_cast<const float4 *>(acts + (long long)(t0 + i) * net.stride + in_off);
-        float4 *d4 = reinterpret_cast<float4 *>(tile + i * ts);
-        for (int j = part; j < KK / 4; j += PT) d4[j] = src[j];   // rows past the batch exist in `acts` (zero)
+    {   // the inputs' way into LDS (the weights stay in flight)
+        static_for<NB_IN>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if (part_ + u * PT < n4) d4[part_ + u * PT] = vin[u];
+        });
     }
     MZ_SSTAMP(slot_, 1)
     __syncthreads();
@@ -592,7 +624,7 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
             for (int i = 0; i < MZ_WPF; i++) {
                 const int k = k0 + i;
                 wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, k < nkb ? lane * 16 + k * 1024 : 0x7ffffff0, w_off, 0));
-                ka[i] = k < nkb ? (q[9] ? k : net.kidx[qw[2] + k]) : 0;
+                ka[i] = k < nkb ? (q_dense ? k : net.kidx[kx_off + k]) : 0;
             }
             mfma_round<2>(nkb - k0 < MZ_WPF ? nkb - k0 : MZ_WPF, a0, a1, wa, ka, acc0, acc1);
         }
@@ -605,7 +637,7 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     if (stop_ == 3) { if (acc0[1] == 12345.678f) acts[0] = 0.0f; return; }
 #endif
     if (col < N) {
-        const int out_off = q[3], skip_off = q[4], actf = q[5];
+        const int out_off = q_out, skip_off = q_skip, actf = q_act;
         const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
         float *o0 = acts + (long long)(t0 + (lane & 15)) * net.stride + col, *o1 = o0 + 16 * (long long)net.stride;
         float v0[4], v1[4];

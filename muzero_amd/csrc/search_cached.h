@@ -67,15 +67,7 @@ __device__ __forceinline__ T np_sum_serial(const T (&x)[A])
     }
 }
 
-// Compile-time loops and field extraction from a record held as 16-byte chunks in registers.
-template <int... I, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
-{
-    (f(std::integral_constant<int, I>()), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>(), f); }
-
+// Field extraction from a record held as 16-byte chunks in registers (compile-time loops: static_for, device_common.h).
 template <int K, int NCH>
 __device__ __forceinline__ uint32_t rec_word(const uint4 (&ch)[NCH])
 {
