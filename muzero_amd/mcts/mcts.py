@@ -124,13 +124,16 @@ class MCTS:
             return cached[1]
         from muzero_amd.packing import pack_network, pack_network_mfma, pack_root_network_mfma
         plan = None
-        packed = pack_network(network)
-        if max(p.weight_bytes() for p in (packed.recurrent, packed.represent, packed.predict)) <= 48 * 1024:
+        # (a representation that torch evaluates - downsampled observation stacks - has no program to pack: the roots
+        # come from network.initial_flat and the simulations run on the matrix cores)
+        torch_rep = getattr(network.rep, 'steps', None) is None
+        packed = None if torch_rep else pack_network(network)
+        if packed is not None and max(p.weight_bytes() for p in (packed.recurrent, packed.represent, packed.predict)) <= 48 * 1024:
             plan = ('fused', packed)
         elif A <= 16:
             pm, io = pack_network_mfma(network)
             if pm.stride * 32 * 4 + 4096 <= 160 * 1024:
-                plan = ('mfma', (pm, io), pack_root_network_mfma(network))
+                plan = ('mfma', (pm, io), None if torch_rep else pack_root_network_mfma(network))
         network._mz_plan = (stamp, plan)
         return plan
 
@@ -163,10 +166,16 @@ class MCTS:
                 eng.set_network(plan[1])
             else:
                 eng.set_network_mfma(*plan[1])
-                eng.set_root_network_mfma(*plan[2])
+                if plan[2] is not None:
+                    eng.set_root_network_mfma(*plan[2])
             eng._plan_of = (id(network), id(plan))
         if plan is not None and plan[0] == 'mfma':
-            logits, hidden, value = eng.initial_inference_mfma(obs.reshape(B, -1))
+            if plan[2] is not None:
+                logits, hidden, value = eng.initial_inference_mfma(obs.reshape(B, -1))
+            else:
+                if network.device != dev:
+                    network.to(dev)
+                logits, hidden, value = network.initial_flat(obs.reshape(B, -1).to(dev))
         # Root noise from the global NumPy stream in the order B consecutive reference searches consume it (their
         # tie-break uniforms aside), drawn in ONE call per batch: a Python-level draw per tree costs more than the
         # search once batches reach thousands of trees.

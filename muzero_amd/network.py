@@ -111,6 +111,48 @@ def _conv3(x, sd, key, stride=1):
     return F.conv2d(x, sd[key].double(), None, stride=stride, padding=1)
 
 
+class TorchRepresentation:
+    """network.py:228-325 with `downsample` on: the DownSample stack (two stride-2 convolutions, eight residual blocks,
+    two average poolings: h x w -> ceil(h/16) x ceil(w/16)) and the residual tower, evaluated by torch's own
+    convolutions in float32 on the network's device.  Observations at full resolution are not lowered to dense
+    programs - a dense matrix over a stack of frames has 10^8..10^9 entries - and the representation runs once per
+    search, at the root; the dynamics and prediction programs, which every simulation evaluates, work on the
+    downsampled state and are lowered like any board network.  Same `run` interface as DenseProgram; `steps` is None."""
+    steps = None
+
+    def __init__(self, sd, cin, h, w, channels, blocks):
+        self.cin, self.h, self.w = cin, h, w
+        p = 'representation_network.downsample_net'
+        self.names = ([p + '.conv1'] + [f'{p}.res_block1.{i}' for i in range(2)] + [p + '.conv2'] +
+                      [f'{p}.res_block2.{i}' for i in range(3)] + ['pool'] + [f'{p}.res_block3.{i}' for i in range(3)] +
+                      ['pool'] + [f'representation_network.res_tower.{i}' for i in range(blocks)])
+        keep = tuple(n + '.' for n in self.names if n != 'pool')
+        self.t = {k: v.float() for k, v in sd.items() if k.startswith(keep) and v.is_floating_point()}
+
+    def to(self, device):
+        self.t = {k: v.to(device) for k, v in self.t.items()}
+        return self
+
+    def _bn(self, x, p):
+        t = self.t
+        return F.batch_norm(x, t[p + '.running_mean'], t[p + '.running_var'], t[p + '.weight'], t[p + '.bias'], False, 0.0, BN_EPS)
+
+    def run(self, inputs):
+        x = inputs['obs'].float().reshape(-1, self.cin, self.h, self.w)
+        for n in self.names:
+            if n == 'pool':
+                x = F.avg_pool2d(x, kernel_size=3, stride=2, padding=1)
+            elif n.endswith(('.conv1', '.conv2')) and '.res_' not in n:
+                x = F.conv2d(x, self.t[n + '.weight'], None, stride=2, padding=1)
+            else:   # utils/network_utils.py:47-68
+                y = F.relu(self._bn(F.conv2d(x, self.t[n + '.conv1.weight'], None, padding=1), n + '.bn1'))
+                x = F.relu(self._bn(F.conv2d(y, self.t[n + '.conv2.weight'], None, padding=1), n + '.bn2') + x)
+        return {'hidden_raw': x.flatten(1)}
+
+    def macs(self) -> int:
+        return 0   # not part of a search's simulations
+
+
 class MuZeroDenseNetwork:
     """A MuZero network compiled to dense programs; same call interface as the reference's
     networks (`initial_inference`, `recurrent_inference`, `set_weights`)."""
@@ -185,15 +227,17 @@ class MuZeroDenseNetwork:
         prog.add(out, out + '_mid', W2, b2, 'relu', skip=inp)
 
     def _compile_resnet(self, sd):
-        """network.py:133-186, 273-402 with downsample off (the only form the reference's games use,
-        main.py:47-48): the board is small, so each conv stretch is one dense matrix."""
+        """network.py:133-186, 228-402: the board (or the downsampled observation) is small, so each conv stretch of
+        the dynamics and prediction networks is one dense matrix; so is the representation of a board game
+        (downsample off, the only form the reference's games use, main.py:47-48)."""
         c = self.config
-        if getattr(c, 'downsample', False):
-            raise NotImplementedError('downsampled observation stacks are not lowered to dense programs; '
-                                      'pass the torch module itself to the search (generic network path)')
         C, (h, w) = int(c.channels), c.observation_dim[1:]
         cin = int(c.n_stacked_observations * c.observation_dim[0])
         self.obs_size = cin * h * w
+        down = bool(getattr(c, 'downsample', False))
+        if down:   # network.py:152-156, 298-304: dynamics and prediction work on the downsampled state
+            rep_torch = TorchRepresentation(sd, cin, h, w, C, int(c.blocks))
+            h, w = math.ceil(h / 16), math.ceil(w / 16)
         self.H = C * h * w
         if self.H + h * w > 4096:
             raise NotImplementedError('board too large for dense lowering')
@@ -204,13 +248,16 @@ class MuZeroDenseNetwork:
             raise ValueError(f'{self.A} actions do not fit a {h}x{w} action plane (one cell per action)')
         blocks = int(c.blocks)
         rep, dyn, pred = DenseProgram(), DenseProgram(), DenseProgram()
-        # representation: ConvBlock + residual tower
-        p = 'representation_network.conv_block.network'
-        W, b = affine_of(lambda x: _bn(_conv3(x, sd, p + '.0.weight'), sd, p + '.1'), (cin, h, w))
-        rep.add('r0' if blocks else 'hidden_raw', 'obs', W, b, 'relu')
-        for i in range(blocks):
-            self._res_block(rep, sd, f'representation_network.res_tower.{i}', f'r{i}',
-                            'hidden_raw' if i == blocks - 1 else f'r{i + 1}', (C, h, w))
+        # representation: ConvBlock + residual tower (downsampled observations: evaluated by torch, see TorchRepresentation)
+        if down:
+            rep = rep_torch
+        else:
+            p = 'representation_network.conv_block.network'
+            W, b = affine_of(lambda x: _bn(_conv3(x, sd, p + '.0.weight'), sd, p + '.1'), (cin, h, w))
+            rep.add('r0' if blocks else 'hidden_raw', 'obs', W, b, 'relu')
+            for i in range(blocks):
+                self._res_block(rep, sd, f'representation_network.res_tower.{i}', f'r{i}',
+                                'hidden_raw' if i == blocks - 1 else f'r{i + 1}', (C, h, w))
         # dynamics: ConvBlock over [hidden, action plane] + tower, reward head conv3x3 -> flatten -> mlp
         p = 'dynamics_network.conv_block.network'
         W, b = affine_of(lambda x: _bn(_conv3(x, sd, p + '.0.weight'), sd, p + '.1'), (C + 1, h, w))
@@ -349,9 +396,21 @@ def random_state_dict(config, seed=None) -> Dict[str, torch.Tensor]:
     if c.network == 'resnet':
         C, (h, w) = int(c.channels), c.observation_dim[1:]
         cin = int(c.n_stacked_observations * c.observation_dim[0])
+        if getattr(c, 'downsample', False):   # network.py:228-260
+            h, w = math.ceil(h / 16), math.ceil(w / 16)
+            p = 'representation_network.downsample_net'
+            sd[p + '.conv1.weight'] = _conv_init(g, C // 2, cin, 3, False)[0]
+            for i in range(2):
+                res(f'{p}.res_block1.{i}', C // 2)
+            sd[p + '.conv2.weight'] = _conv_init(g, C, C // 2, 3, False)[0]
+            for i in range(3):
+                res(f'{p}.res_block2.{i}', C)
+            for i in range(3):
+                res(f'{p}.res_block3.{i}', C)
+        else:
+            sd['representation_network.conv_block.network.0.weight'] = _conv_init(g, C, cin, 3, False)[0]
+            bn('representation_network.conv_block.network.1', C)
         res_sz = h * w
-        sd['representation_network.conv_block.network.0.weight'] = _conv_init(g, C, cin, 3, False)[0]
-        bn('representation_network.conv_block.network.1', C)
         for i in range(int(c.blocks)):
             res(f'representation_network.res_tower.{i}', C)
         sd['dynamics_network.conv_block.network.0.weight'] = _conv_init(g, C, C + 1, 3, False)[0]

@@ -107,10 +107,13 @@ class BatchedSelfPlay:
         if hasattr(network, 'recurrent_flat'):
             from .packing import pack_network, pack_network_mfma, pack_root_network_mfma
             H = network.H
-            packed = pack_network(network)
+            # (a representation evaluated by torch - downsampled observation stacks - has no program to pack)
+            self._torch_root = getattr(network.rep, 'steps', None) is None
+            packed = None if self._torch_root else pack_network(network)
             self.engine = _engine.SearchEngine(config, H, B, seed=seed, noise_mode=noise_mode, device=self.device)
             lanes_groups = 256 // 16
-            fits = (packed.recurrent.weight_bytes() + lanes_groups * packed.recurrent.scratch * 4 < 150 * 1024 and
+            fits = (packed is not None and
+                    packed.recurrent.weight_bytes() + lanes_groups * packed.recurrent.scratch * 4 < 150 * 1024 and
                     packed.represent.weight_bytes() + packed.predict.weight_bytes() < 100 * 1024)
             if fits:
                 self.engine.set_network(packed)
@@ -118,7 +121,8 @@ class BatchedSelfPlay:
             else:
                 network.to(self.device)
                 self.engine.set_network_mfma(*pack_network_mfma(network))
-                self.engine.set_root_network_mfma(*pack_root_network_mfma(network))   # the roots, too, on the device
+                if not self._torch_root:
+                    self.engine.set_root_network_mfma(*pack_root_network_mfma(network))   # the roots, too, on the device
                 self.mode = 'mfma'
         else:
             self.engine = None  # created on the first step, once the hidden size is known
@@ -172,7 +176,7 @@ class BatchedSelfPlay:
             net = self.network
             with torch.no_grad():
                 if self.mode == 'mfma':
-                    lg, hid, val = eng.initial_inference_mfma(e.search_obs)
+                    lg, hid, val = net.initial_flat(e.search_obs) if self._torch_root else eng.initial_inference_mfma(e.search_obs)
                 else:
                     shape = getattr(net, 'observation_shape', None)
                     obs = e.search_obs.cpu().reshape(self.B, *shape) if shape else e.search_obs.cpu()

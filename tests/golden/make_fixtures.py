@@ -378,6 +378,38 @@ def gen_network_fixtures():
         print(f'net_{name}.npz')
 
 
+def downsample_net_config():
+    return SimpleNamespace(network='resnet', observation_dim=[3, 48, 48], n_actions=9, n_stacked_observations=1,
+                           blocks=1, channels=16, reduced_channels_reward=4, reduced_channels_policy=4,
+                           reduced_channels_value=4, resnet_fc_reward_layers=[16], resnet_fc_policy_layers=[16],
+                           resnet_fc_value_layers=[16], downsample=True, support_limit=5)
+
+
+def gen_downsample_fixture():
+    """The reference's residual network with `downsample` on (network.py:228-325): 48 x 48 frames -> a 3 x 3 state."""
+    ncfg = downsample_net_config()
+    set_seed(0)
+    net = ref_network.MuZeroNetwork(ncfg)
+    randomize_bn(net, 2)
+    net.eval()
+    out = {'sd_' + k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    rng = np.random.RandomState(11)
+    B = 4
+    obs = rng.uniform(0.0, 1.0, size=(B, 3, 48, 48)).astype(np.float32)
+    actions = rng.randint(0, 9, size=B)
+    with torch.no_grad():
+        lg, hid, val = net.initial_inference(torch.as_tensor(obs))
+        enc = torch.zeros(B, 3, 3)
+        enc.view(B, 9)[torch.arange(B), torch.as_tensor(actions)] = 1
+        lg2, hid2, val2, rew2 = net.recurrent_inference(hid, enc)
+        lg3, hid3, val3, rew3 = net.recurrent_inference(hid2, enc)
+    out.update(obs=obs, actions=actions, init_logits=lg.numpy(), init_hidden=hid.numpy(), init_value=val.numpy(),
+               rec_logits=lg2.numpy(), rec_hidden=hid2.numpy(), rec_value=val2.numpy(), rec_reward=rew2.numpy(),
+               rec2_logits=lg3.numpy(), rec2_hidden=hid3.numpy(), rec2_value=val3.numpy(), rec2_reward=rew3.numpy())
+    np.savez_compressed(os.path.join(HERE, 'net_resnet_downsample.npz'), **out)
+    print('net_resnet_downsample.npz')
+
+
 # ---------------------------------------------------------------------- misc known answers
 
 def _find_filling_win():
@@ -802,6 +834,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         gen_trainer()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'downsample':
+        gen_downsample_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'stacking':
         gen_stacking()
         sys.exit(0)
@@ -825,3 +860,4 @@ if __name__ == '__main__':
     gen_hash_fixtures()
     gen_stream_fixtures()
     gen_network_fixtures()
+    gen_downsample_fixture()

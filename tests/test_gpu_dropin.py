@@ -171,6 +171,46 @@ def test_dense_network_batched_search_on_gpu(mcts_pkg):
         np.testing.assert_allclose(tree.node_values, z[p + 'node_values'], atol=1e-5)
 
 
+def test_downsampled_network_searches_on_the_matrix_cores(mcts_pkg):
+    """`downsample` on (network.py:228-325): roots from the torch-evaluated representation, every simulation's leaf on
+    the matrix cores, against the same search with torch evaluating every leaf (the generic path, taken for a network
+    object that only has the reference's two inference calls).  Same Gumbel noise for both; the leaf evaluators agree
+    to float32 rounding, so nearly all trees are identical and the rest differ by a late visit."""
+    m = mcts_pkg[0]
+    from test_network_lowering import load_net
+
+    class TwoCalls:   # what a reference network offers, nothing the lowering recognises
+        def __init__(self, net):
+            self.net, self.device = net, net.device
+
+        def initial_inference(self, obs):
+            return self.net.initial_inference(obs)
+
+        def recurrent_inference(self, h, a):
+            return self.net.recurrent_inference(h, a)
+
+    z, net = load_net('resnet_downsample')
+    net.to('cuda')
+    A, S, B = 9, 30, 64
+    cfg = make_config(True, A, S, 1, 0.997)
+    rng = np.random.RandomState(3)
+    obs = rng.uniform(0.0, 1.0, size=(B, 3, 48, 48)).astype(np.float32)
+    legal, tp = np.ones((B, A)), np.zeros(B, np.int32)
+    out = []
+    for network in (net, TwoCalls(net)):
+        np.random.seed(17)
+        search = m.MCTS(cfg)
+        actions, values, probs = search.search_batch(network, obs, legal, tp, action_encoder=lambda a: np.eye(9)[a].reshape(3, 3))
+        trees = [search.last_tree(b) for b in range(B)]
+        out.append((np.asarray(actions), np.asarray(values), np.asarray(probs), np.stack([t.children_visits[0] for t in trees])))
+    assert m.MCTS._lowered_plan(net, A)[0] == 'mfma' and m.MCTS._lowered_plan(net, A)[2] is None
+    same = (out[0][3] == out[1][3]).all(axis=1)
+    assert same.mean() >= 0.9, same.mean()
+    assert np.array_equal(out[0][0][same], out[1][0][same])
+    np.testing.assert_allclose(out[0][1][same], out[1][1][same], atol=1e-5, rtol=0)
+    assert (out[0][3].sum(axis=1) == S).all()
+
+
 def test_reference_style_module_is_lowered_once_per_weight_version(mcts_pkg):
     """An eval-mode nn.Module with the reference's state_dict layout takes the single-launch path: it is
     lowered on first use, reused while its weights are untouched, lowered again after an in-place update."""

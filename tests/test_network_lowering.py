@@ -25,6 +25,11 @@ def net_config(name):
         return SimpleNamespace(network='mlp', observation_dim=[1, 1, 4], n_actions=2, n_stacked_observations=1,
                                encoding_size=8, fc_reward_layers=[16], fc_policy_layers=[16], fc_value_layers=[16],
                                fc_representation_layers=[], fc_hidden_state_layers=[16], support_limit=10)
+    if name == 'resnet_downsample':
+        return SimpleNamespace(network='resnet', observation_dim=[3, 48, 48], n_actions=9, n_stacked_observations=1,
+                               blocks=1, channels=16, reduced_channels_reward=4, reduced_channels_policy=4,
+                               reduced_channels_value=4, resnet_fc_reward_layers=[16], resnet_fc_policy_layers=[16],
+                               resnet_fc_value_layers=[16], downsample=True, support_limit=5)
     return SimpleNamespace(network='mlp', observation_dim=[1, 1, 32], n_actions=18, n_stacked_observations=1,
                            encoding_size=64, fc_reward_layers=[64], fc_policy_layers=[64], fc_value_layers=[64],
                            fc_representation_layers=[], fc_hidden_state_layers=[64], support_limit=30)
@@ -36,7 +41,7 @@ def load_net(name):
     return z, MuZeroNetwork(net_config(name), sd)
 
 
-@pytest.mark.parametrize('name', ['mlp_cartpole', 'resnet_tictactoe', 'mlp_synthetic'])
+@pytest.mark.parametrize('name', ['mlp_cartpole', 'resnet_tictactoe', 'mlp_synthetic', 'resnet_downsample'])
 def test_inference_matches_reference_modules(name):
     z, net = load_net(name)
     obs = torch.as_tensor(z['obs'], dtype=torch.float32)
@@ -114,6 +119,18 @@ def test_packed_program_checker_matches_reference_outputs(name):
     np.testing.assert_allclose(nh, z['rec_hidden'].reshape(nh.shape), atol=HTOL, rtol=0)
     np.testing.assert_allclose(val, z['rec_value'], atol=TOL, rtol=0)
     np.testing.assert_allclose(rew, z['rec_reward'], atol=TOL, rtol=0)
+
+
+def test_downsampled_network_lowers_dynamics_and_prediction_only():
+    """`downsample` on (network.py:228-325): the representation stays a stack of torch convolutions over the full
+    frames, the programs every simulation runs are dense matrices over the 3 x 3 downsampled state, and a random
+    checkpoint has the reference's parameter names and shapes."""
+    z, net = load_net('resnet_downsample')
+    assert net.rep.steps is None and net.hidden_shape == (16, 3, 3) and net.obs_size == 3 * 48 * 48
+    assert all(s.W.shape[1] <= 16 * 9 + 9 for s in list(net.dyn.steps) + list(net.pred.steps))
+    sd = random_state_dict(net_config('resnet_downsample'), seed=3)
+    ref = {k[3:]: z[k].shape for k in z.files if k.startswith('sd_')}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == ref
 
 
 def test_action_plane_smaller_than_action_count_is_rejected():
