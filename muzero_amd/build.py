@@ -14,15 +14,22 @@ SOURCES = ['engine.hip', 'mfma_kernels.hip', 'chain_kernels.hip', 'cached_kernel
            'cached_kernels_c.hip']
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'muzero_amd.h')]
 # -ffp-contract=off: the tree arithmetic must round exactly like the reference's NumPy expressions.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17']
+FLAGS = ['--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-std=c++17']
+# Optimisation level per translation unit, as measured (same box, both builds): the whole-search kernels of the matrix-core
+# units are larger than the 64 KB instruction cache, and optimising for size makes them 0.7 - 0.9 % faster (TicTacToe
+# 16384 x 100: 7.15 -> 7.10 ms, Atari-shaped 1024 x 200: 7.84 -> 7.78 ms); the register-resident tree kernels of
+# engine.hip lose 6 % that way (CartPole 256 x 50) and stay at -O3.
+OPT = {'engine.hip': '-O3', 'chain_kernels.hip': '-O3'}
+OPT_DEFAULT = '-Os'
 
 
 def source_fingerprint() -> str:
-    """sha256 (16 hex digits) over the kernel sources - every .hip and .h under csrc/ and the public header - in name
-    order.  Measurements that belong to one state of the kernels (HBM traffic from the counter passes) carry it, so
+    """sha256 (16 hex digits) over the compiler flags and the kernel sources - every .hip and .h under csrc/ and the
+    public header - in name order.  Measurements that belong to one state of the kernels (HBM traffic from the counter passes) carry it, so
     that a reader can tell whether they still describe the code at hand."""
     import hashlib
     h = hashlib.sha256()
+    h.update(repr((FLAGS, sorted(OPT.items()), OPT_DEFAULT)).encode())   # the same sources built differently are other kernels
     for f in sorted(SOURCES + HEADERS):
         h.update(os.path.basename(f).encode())
         with open(os.path.join(CSRC, f), 'rb') as fh:
@@ -67,7 +74,8 @@ def build(force: bool = False, defines=(), lib: str = LIB) -> str:
 
         def compile_one(pair):
             src, obj = pair
-            subprocess.check_call([hipcc, *FLAGS, *[f'-D{x}' for x in defines], '-c', os.path.join(CSRC, src), '-o', obj])
+            subprocess.check_call([hipcc, *FLAGS, OPT.get(src, OPT_DEFAULT), *[f'-D{x}' for x in defines], '-c',
+                                   os.path.join(CSRC, src), '-o', obj])
         with ThreadPoolExecutor(max(len(todo), 1)) as pool:
             list(pool.map(compile_one, todo))
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib])

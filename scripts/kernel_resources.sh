@@ -5,8 +5,9 @@
 cd "$(dirname "$0")/.."
 echo "kernel | SGPRs | VGPRs | AGPRs | scratch bytes/lane | waves/SIMD | SGPR spills | VGPR spills | static LDS bytes/block"
 for tu in engine mfma_kernels chain_kernels cached_kernels_a cached_kernels_b cached_kernels_c; do
-    echo "== muzero_amd/csrc/$tu.hip"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 --offload-device-only -c \
+    opt=$(python3 -c "import sys; sys.path.insert(0, '.'); from muzero_amd.build import OPT, OPT_DEFAULT; print(OPT.get('$tu.hip', OPT_DEFAULT))")
+    echo "== muzero_amd/csrc/$tu.hip ($opt)"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 $opt -ffp-contract=off -std=c++17 --offload-device-only -c \
         -Rpass-analysis=kernel-resource-usage muzero_amd/csrc/$tu.hip -o /tmp/mz_${tu}_dev.o 2>&1 |
         awk -v pat="${1:-.}" '
             /Function Name:/ { name = $0; sub(/^.*Function Name: /, "", name); sub(/ \[-Rpass.*$/, "", name); keep = (name ~ pat); n = 0; next }
