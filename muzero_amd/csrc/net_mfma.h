@@ -79,6 +79,7 @@ __device__ __forceinline__ float4 as_float4(u32x4 v)
 
 struct NetBufs {
     __amdgpu_buffer_rsrc_t w, b;
+    const char *wbase;   // the weight fragments, for descriptors of a single job's blocks
 };
 
 __device__ __forceinline__ NetBufs net_bufs(const MfmaNet &net)
@@ -86,6 +87,7 @@ __device__ __forceinline__ NetBufs net_bufs(const MfmaNet &net)
     NetBufs r;
     r.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(net.wfrag), 0, net.w_bytes, 0x00020000);
     r.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(net.bias), 0, net.b_bytes, 0x00020000);
+    r.wbase = reinterpret_cast<const char *>(net.wfrag);
     return r;
 }
 
@@ -114,11 +116,12 @@ __device__ __forceinline__ void tile_wload(const NetBufs &nb, const TileSched &t
     const int jj = real ? job : 0;
     const int w_off = sched_get(ts, 0, jj), nkb = real ? sched_get(ts, 1, jj) : 0, b_col = sched_get(ts, 7, jj);
     const int ncols = real ? sched_get(ts, 8, jj) : 0;
+    // a descriptor of exactly this job's blocks: the hardware drops the loads behind them, so the addresses are the
+    // same for every job (one register and immediate offsets) where a per-load select cost three instructions each
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(nb.wbase) + w_off, 0, nkb * 1024, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < MZ_WPF; i++) {
-        const int voff = i < nkb ? lane * 16 + i * 1024 : 0x7ffffff0;
-        r.w[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, voff, w_off, 0));
-    }
+    for (int i = 0; i < MZ_WPF; i++)
+        r.w[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + i * 1024, 0, 0));
     const int boff = ncols > 0 ? (lane >> 4) * 16 : 0x7ffffff0;   // (the bias array is padded to whole tiles of 16)
     r.bias = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.b, boff, b_col * 4, 0));
 }
@@ -585,15 +588,15 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     });
     __builtin_amdgcn_sched_barrier(0);   // (the compiler would move these loads down to their stores, behind the weights)
     float4 wa[MZ_WPF], wb[MZ_WPF];
+    // (a descriptor of exactly this wave's blocks: the hardware drops the loads behind them)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(nb.wbase) + w_off, 0, nkb * 1024, 0x00020000);
 #pragma unroll
     for (int i = 0; i < MZ_WPF; i++)
-        wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, i < nkb ? lane * 16 + i * 1024 : 0x7ffffff0, w_off, 0));
+        wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + i * 1024, 0, 0));
     if constexpr (KB > MZ_WPF) {
 #pragma unroll
-        for (int i = 0; i < MZ_WPF; i++) {
-            const int k = MZ_WPF + i;
-            wb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, k < nkb ? lane * 16 + k * 1024 : 0x7ffffff0, w_off, 0));
-        }
+        for (int i = 0; i < MZ_WPF; i++)
+            wb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (MZ_WPF + i) * 1024, 0, 0));
     }
     // (result layout as in tile_job: tree = lane & 15, output columns (lane >> 4) * 4 .. + 3 down the registers)
     const int col = (q_ct0 + (active ? wave : 0)) * 16 + (lane >> 4) * 4, N = q_n;
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
 #pragma unroll
             for (int i = 0; i < MZ_WPF; i++) {
                 const int k = k0 + i;
-                wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.w, k < nkb ? lane * 16 + k * 1024 : 0x7ffffff0, w_off, 0));
+                wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + k * 1024, 0, 0));
                 ka[i] = k < nkb ? (q_dense ? k : net.kidx[kx_off + k]) : 0;
             }
             mfma_round<2>(nkb - k0 < MZ_WPF ? nkb - k0 : MZ_WPF, a0, a1, wa, ka, acc0, acc1);
