@@ -536,15 +536,28 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     // the tree tile is the fast one, so a tile's rows of `acts` are read and written through one XCD's L2 by all the
     // column blocks that use them (the weights, needed by every tile, travel to every L2 either way)
     const int job_ = blockIdx.y, tile_ = blockIdx.x;
-    const int32_t *q = desc + MZ_LVL_DESC * job_;
+    // (whatever depends on kernel arguments alone is computed here, in front of the descriptor: the compiler loads an
+    // argument in the block of its first use, and an argument first used behind the descriptor costs one more round trip
+    // to memory in front of the first load of data)
+    const NetBufs nb = net_bufs(net);
+    const int t0 = row_first + tile_ * 32;
+    const float *in_row = acts + (long long)(t0 + tid / PT) * net.stride;
+    // (... and the arguments are tied into the descriptor's address - by a term that is zero for every valid launch
+    // (positive stride and first row, addresses below 2^63) but not for the compiler - because computing with them here
+    // is not enough: the compiler moves such computations, and the argument loads with them, down to their uses)
+    const int tie_ = (net.stride >> 31) | (row_first >> 31) | (int)(reinterpret_cast<uintptr_t>(net.wfrag) >> 63) |
+                     (int)(reinterpret_cast<uintptr_t>(net.bias) >> 63) | (int)(reinterpret_cast<uintptr_t>(acts) >> 63);
+    const int32_t *q = desc + MZ_LVL_DESC * job_ + tie_;
     // (every field is read here, before the kernel's first store: behind a store through a generic pointer the compiler
     // no longer takes these wave-uniform reads for scalar loads, and a vector load's wait covers the weights in flight)
     const int KK = q[0], ts = KK + 4, in_off = q[1];
     const int q_n = q[2], q_out = q[3], q_skip = q[4], q_act = q[5], q_bias = q[6], q_ct0 = q[8], q_dense = q[9];
-    const int t0 = row_first + tile_ * 32;
+    // (the wave's own three fields at an address that does not depend on the block's: one round trip to memory for both;
+    // the entries of waves a block does not have are zero)
+    const int32_t *qw = q + 10 + 3 * wave;
+    const int w_off = qw[0], nkb_w = qw[1], kx_off = qw[2];
     const bool active = wave < q[7];
-    const int32_t *qw = q + 10 + 3 * (active ? wave : 0);
-    const int w_off = qw[0], nkb = active ? qw[1] : 0, kx_off = qw[2];
+    const int nkb = active ? nkb_w : 0;
     int ka[MZ_WPF], kb[MZ_WPF];
     if (q_dense) {   // every column tile of the block multiplies input blocks 0, 1, 2, ...: no index list to fetch
 #pragma unroll
@@ -557,7 +570,6 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
             kb[i] = (KB > MZ_WPF && MZ_WPF + i < nkb) ? kx[MZ_WPF + i] : 0;
         }
     }
-    const NetBufs nb = net_bufs(net);
     // The trees' inputs are asked for FIRST and the weights behind them: loads come back in the order they were issued,
     // and every wave needs the whole input tile (through LDS, behind the barrier) before its first matrix instruction,
     // but its weight blocks only one after the other - so the weights stream in while the inputs are parked in LDS and
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     // loads leave together, indices past the end of the row clamped: NB_IN of them cover layers of up to 384 inputs.
     constexpr int NB_IN = (96 + PT - 1) / PT;
     const int part_ = tid % PT, n4 = KK / 4;
-    const f32x4 *src4 = reinterpret_cast<const f32x4 *>(acts + (long long)(t0 + tid / PT) * net.stride + in_off);
+    const f32x4 *src4 = reinterpret_cast<const f32x4 *>(in_row + in_off);
     f32x4 *d4 = reinterpret_cast<f32x4 *>(tile + (tid / PT) * ts);
     // (wider layers: the rest of a row goes first, round by round - with loads of unknown number in flight the compiler
     // would make the first matrix instruction wait for every load, the weights included)
