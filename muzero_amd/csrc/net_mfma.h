@@ -773,7 +773,15 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     // XCD (within whole groups of 64 blocks, the two 3-bit fields of the index change places).
     unsigned vb = blockIdx.x;
     if ((vb | 63u) < gridDim.x) vb = (vb & ~63u) | ((vb & 7u) << 3) | ((vb >> 3) & 7u);
-    const int t = t_first + (int)((vb * (unsigned)MZ_BLOCK + threadIdx.x) / 64), a = threadIdx.x % 64;
+    // (kernel arguments of every 64-byte line of the argument block tied into the tree index - by a term that is zero
+    // for every valid launch but not for the compiler - so that all of them are asked for at once: the compiler loads an
+    // argument in front of its first use, and the lines first used later each cost a round trip to memory of their own)
+    auto top_bit = [](const void *p) { return (int)(reinterpret_cast<uintptr_t>(p) >> 63); };
+    const int tie_ = top_bit(d.sel_parent) | top_bit(d.path) | top_bit(d.dec) | top_bit(d.c_table) | top_bit(d.sqrt_table) |
+                     top_bit(d.err) | top_bit(d.visit_total) | top_bit(d.noise_calls) | top_bit(noise) | top_bit(acts) |
+                     top_bit(net.wfrag) | (d.B >> 31) | (d.L.S >> 31) | (select_next >> 31) | (leaf >> 31) |
+                     (noise_max_calls >> 31) | (net.stride >> 31) | (net.io[9] >> 31);
+    const int t = t_first + tie_ + (int)((vb * (unsigned)MZ_BLOCK + threadIdx.x) / 64), a = threadIdx.x % 64;
     const bool on = a < d.L.A;
     // the pending selection is asked for before the tables are staged: both waits overlap
     int parent = 0, action = 0, ntp = 0, depth = 0;
