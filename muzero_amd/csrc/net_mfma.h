@@ -163,6 +163,54 @@ __device__ __forceinline__ void mfma_blocks(const float *a0, const float *a1, co
     }
 }
 
+// The same with a call behind every block: a plain loop with a constant trip count, unrolled, so that `i` is a constant
+// inside `after` as well.
+template <int NKB, int I = 0, class After>
+__device__ __forceinline__ void mfma_blocks_hooked(const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
+                                                   const int (&kb)[MZ_WPF], f32x4 &acc0, f32x4 &acc1, float4 x0, float4 x1,
+                                                   After &after)
+{
+    if constexpr (I < NKB) {
+        float4 n0 = x0, n1 = x1;
+        if constexpr (I + 1 < NKB) {
+            n0 = *reinterpret_cast<const float4 *>(a0 + kb[I + 1] * 16);
+            n1 = *reinterpret_cast<const float4 *>(a1 + kb[I + 1] * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of block I + 1 ahead of block I's matrix instructions
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].x, x0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].x, x1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].y, x0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].y, x1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].z, x0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].z, x1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].w, x0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].w, x1.w, acc1, 0, 0, 0);
+        after(std::integral_constant<int, I>());
+        mfma_blocks_hooked<NKB, I + 1>(a0, a1, w, kb, acc0, acc1, n0, n1, after);
+    }
+}
+
+// n blocks (1..MZ_WPF) of a 32-tree tile with a call behind every block
+template <class After>
+__device__ __forceinline__ void mfma_round_hooked(int n, const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
+                                                  const int (&kb)[MZ_WPF], f32x4 &acc0, f32x4 &acc1, After after)
+{
+    const float4 x0 = *reinterpret_cast<const float4 *>(a0 + kb[0] * 16), x1 = *reinterpret_cast<const float4 *>(a1 + kb[0] * 16);
+    switch (n) {
+    case 1: mfma_blocks_hooked<1>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 2: mfma_blocks_hooked<2>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 3: mfma_blocks_hooked<3>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 4: mfma_blocks_hooked<4>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 5: mfma_blocks_hooked<5>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 6: mfma_blocks_hooked<6>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 7: mfma_blocks_hooked<7>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 8: mfma_blocks_hooked<8>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 9: mfma_blocks_hooked<9>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 10: mfma_blocks_hooked<10>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    default: break;
+    }
+}
+
 template <int HALVES>
 __device__ __forceinline__ void mfma_round(int n, const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
                                            const int (&kb)[MZ_WPF], f32x4 &acc0, f32x4 &acc1)
@@ -547,6 +595,10 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     // is not enough: the compiler moves such computations, and the argument loads with them, down to their uses)
     const int tie_ = (net.stride >> 31) | (row_first >> 31) | (int)(reinterpret_cast<uintptr_t>(net.wfrag) >> 63) |
                      (int)(reinterpret_cast<uintptr_t>(net.bias) >> 63) | (int)(reinterpret_cast<uintptr_t>(acts) >> 63);
+#ifdef MZ_STAMPS
+    // diagnostic build: when the kernel arguments have arrived (slot 4) and when the descriptor has (slot 5)
+    if (slot_ >= 0 && tie_ == 0) mz_dbg_stamps[slot_ * 8 + 4] = clock64() - kst_;
+#endif
     const int32_t *q = desc + MZ_LVL_DESC * job_ + tie_;
     // (every field is read here, before the kernel's first store: behind a store through a generic pointer the compiler
     // no longer takes these wave-uniform reads for scalar loads, and a vector load's wait covers the weights in flight)
@@ -558,6 +610,9 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     const int w_off = qw[0], nkb_w = qw[1], kx_off = qw[2];
     const bool active = wave < q[7];
     const int nkb = active ? nkb_w : 0;
+#ifdef MZ_STAMPS
+    if (slot_ >= 0 && nkb + KK + kx_off >= 0) mz_dbg_stamps[slot_ * 8 + 5] = clock64() - kst_;
+#endif
     int ka[MZ_WPF], kb[MZ_WPF];
     if (q_dense) {   // every column tile of the block multiplies input blocks 0, 1, 2, ...: no index list to fetch
 #pragma unroll
@@ -602,14 +657,14 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     float4 wa[MZ_WPF], wb[MZ_WPF];
     // (a descriptor of exactly this wave's blocks: the hardware drops the loads behind them)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(nb.wbase) + w_off, 0, nkb * 1024, 0x00020000);
+    // Only the first MZ_LVL_AHEAD blocks are asked for here; block i + MZ_LVL_AHEAD is asked for behind the matrix
+    // instructions of block i.  A compute unit's vector-memory path takes 64 bytes per cycle: a block's 26 loads of 1 KB
+    // per wave occupy it for 3.3 k cycles, during which - issued all at once - its waves sat in front of the barrier.
+    constexpr int AHEAD = MZ_LVL_AHEAD;
+    static_assert(AHEAD >= 1 && AHEAD <= MZ_WPF, "blocks asked for before the barrier");
+    auto wload = [&](int k) { return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + k * 1024, 0, 0)); };
 #pragma unroll
-    for (int i = 0; i < MZ_WPF; i++)
-        wa[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + i * 1024, 0, 0));
-    if constexpr (KB > MZ_WPF) {
-#pragma unroll
-        for (int i = 0; i < MZ_WPF; i++)
-            wb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (MZ_WPF + i) * 1024, 0, 0));
-    }
+    for (int i = 0; i < AHEAD; i++) wa[i] = wload(i);
     // (result layout as in tile_job: tree = lane & 15, output columns (lane >> 4) * 4 .. + 3 down the registers)
     const int col = (q_ct0 + (active ? wave : 0)) * 16 + (lane >> 4) * 4, N = q_n;
     float4 bias4 = {0, 0, 0, 0};
@@ -630,9 +685,18 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     if (!active) return;
     const float *a0 = tile + (lane & 15) * ts + (lane >> 4) * 4, *a1 = a0 + 16 * ts;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    mfma_round<2>(nkb < MZ_WPF ? nkb : MZ_WPF, a0, a1, wa, ka, acc0, acc1);
+    // (blocks the wave does not have are addressed out of range: dropped by the hardware, zeros in the registers)
+    mfma_round_hooked(nkb < MZ_WPF ? nkb : MZ_WPF, a0, a1, wa, ka, acc0, acc1, [&](auto I) {
+        constexpr int k = decltype(I)::value + AHEAD;
+        if constexpr (k < MZ_WPF) wa[k] = wload(k);
+        else if constexpr (KB > MZ_WPF) wb[k - MZ_WPF] = wload(k);
+    });
     if constexpr (KB > MZ_WPF) {
-        if (nkb > MZ_WPF) mfma_round<2>((nkb < KB ? nkb : KB) - MZ_WPF, a0, a1, wb, kb, acc0, acc1);
+        if (nkb > MZ_WPF)
+            mfma_round_hooked((nkb < KB ? nkb : KB) - MZ_WPF, a0, a1, wb, kb, acc0, acc1, [&](auto I) {
+                constexpr int k = decltype(I)::value + AHEAD;
+                if constexpr (k < MZ_WPF) wb[k] = wload(MZ_WPF + k);
+            });
         // layers wider than KB blocks: further rounds, requested here (their latency is exposed)
         for (int k0 = KB; k0 < nkb; k0 += MZ_WPF) {
 #pragma unroll

@@ -34,7 +34,8 @@ lv = ['descriptor + loads issued', 'inputs copied to LDS', 'barrier', 'matrix in
 for l in range(2):
     x = buf[l * 256:(l + 1) * 256, :4]
     print(f'k_net_level_rows level {l}, cycles per block (mean / max over 256 blocks): ' +
-          '  '.join('%s %.0f/%.0f' % (n, v, w) for n, v, w in zip(lv, x.mean(0), x.max(0))))
+          '  '.join('%s %.0f/%.0f' % (n, v, w) for n, v, w in zip(lv, x.mean(0), x.max(0))) +
+          '  (since the kernel began: arguments there after %.0f, descriptor after %.0f)' % tuple(buf[l * 256:(l + 1) * 256, 4:6].mean(0)))
 tr = ['selection + tables', 'epilogue', 'expansion + backup', 'descent', 'inputs staged']
 x = buf[512:768]
 print('k_leaf_backup_select (last simulation but one), cycles per block: ' +
