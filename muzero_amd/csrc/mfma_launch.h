@@ -51,7 +51,7 @@ hipError_t launch_search_gcache(int tm, hipStream_t st, const Dev &d, const Mfma
 #define MZ_LVL_DESC 40  // ints per block descriptor of k_net_level_rows: KK, in_off, N, out_off, skip_off, act, bias_off,
                         // n column tiles, first column tile, dense flag, then per wave: weight byte offset, blocks, kidx offset
 static_assert(MZ_LVL_DESC >= 10 + 3 * MZ_LVL_WAVES, "a block descriptor holds three ints per wave after its ten header ints");
-#define MZ_LVL_AHEAD 6 // ... of which it requests this many before its barrier, the others one by one behind the blocks that multiply
+#define MZ_LVL_AHEAD 3 // ... of which it requests this many before its barrier, the others one by one behind the blocks that multiply
 #define MZ_LVL_KB 20   // weight blocks of a column tile that k_net_level_rows requests before it copies its inputs
 hipError_t launch_net_level_rows(unsigned n_jobs, unsigned n_row_tiles, int max_k16, hipStream_t st, const MfmaNet &net,
                                  const int32_t *desc, float *acts, int row_first, int level);
