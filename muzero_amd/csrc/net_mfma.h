@@ -163,9 +163,10 @@ __device__ __forceinline__ void mfma_blocks(const float *a0, const float *a1, co
     }
 }
 
-// The same with a call behind every block: a plain loop with a constant trip count, unrolled, so that `i` is a constant
-// inside `after` as well.
-template <int NKB, int I = 0, class After>
+// The same with a call behind every block - after(integral_constant<int, i>) behind the matrix instructions of block i,
+// after(integral_constant<int, 100 + NKB>) behind the last block - written as a recursion so that the block's number
+// is a constant inside `after` (the callers ask for later weights there).
+template <int NKB, int HALVES, int I = 0, class After>
 __device__ __forceinline__ void mfma_blocks_hooked(const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
                                                    const int (&kb)[MZ_WPF], f32x4 &acc0, f32x4 &acc1, float4 x0, float4 x1,
                                                    After &after)
@@ -174,40 +175,44 @@ __device__ __forceinline__ void mfma_blocks_hooked(const float *a0, const float 
         float4 n0 = x0, n1 = x1;
         if constexpr (I + 1 < NKB) {
             n0 = *reinterpret_cast<const float4 *>(a0 + kb[I + 1] * 16);
-            n1 = *reinterpret_cast<const float4 *>(a1 + kb[I + 1] * 16);
+            if constexpr (HALVES == 2) n1 = *reinterpret_cast<const float4 *>(a1 + kb[I + 1] * 16);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads of block I + 1 ahead of block I's matrix instructions
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].x, x0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].x, x1.x, acc1, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].x, x1.x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].y, x0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].y, x1.y, acc1, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].y, x1.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].z, x0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].z, x1.z, acc1, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].z, x1.z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].w, x0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].w, x1.w, acc1, 0, 0, 0);
+        if constexpr (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[I].w, x1.w, acc1, 0, 0, 0);
         after(std::integral_constant<int, I>());
-        mfma_blocks_hooked<NKB, I + 1>(a0, a1, w, kb, acc0, acc1, n0, n1, after);
+        mfma_blocks_hooked<NKB, HALVES, I + 1>(a0, a1, w, kb, acc0, acc1, n0, n1, after);
+    } else {
+        after(std::integral_constant<int, 100 + NKB>());
     }
 }
 
-// n blocks (1..MZ_WPF) of a 32-tree tile with a call behind every block
-template <class After>
+// n blocks (0..MZ_WPF) with the calls described above (n = 0: only the closing call)
+template <int HALVES, class After>
 __device__ __forceinline__ void mfma_round_hooked(int n, const float *a0, const float *a1, const float4 (&w)[MZ_WPF],
                                                   const int (&kb)[MZ_WPF], f32x4 &acc0, f32x4 &acc1, After after)
 {
-    const float4 x0 = *reinterpret_cast<const float4 *>(a0 + kb[0] * 16), x1 = *reinterpret_cast<const float4 *>(a1 + kb[0] * 16);
+    const float4 x0 = *reinterpret_cast<const float4 *>(a0 + kb[0] * 16);
+    float4 x1 = {0, 0, 0, 0};
+    if constexpr (HALVES == 2) x1 = *reinterpret_cast<const float4 *>(a1 + kb[0] * 16);
     switch (n) {
-    case 1: mfma_blocks_hooked<1>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 2: mfma_blocks_hooked<2>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 3: mfma_blocks_hooked<3>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 4: mfma_blocks_hooked<4>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 5: mfma_blocks_hooked<5>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 6: mfma_blocks_hooked<6>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 7: mfma_blocks_hooked<7>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 8: mfma_blocks_hooked<8>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 9: mfma_blocks_hooked<9>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    case 10: mfma_blocks_hooked<10>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
-    default: break;
+    case 1: mfma_blocks_hooked<1, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 2: mfma_blocks_hooked<2, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 3: mfma_blocks_hooked<3, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 4: mfma_blocks_hooked<4, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 5: mfma_blocks_hooked<5, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 6: mfma_blocks_hooked<6, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 7: mfma_blocks_hooked<7, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 8: mfma_blocks_hooked<8, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 9: mfma_blocks_hooked<9, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    case 10: mfma_blocks_hooked<10, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
+    default: mfma_blocks_hooked<0, HALVES>(a0, a1, w, kb, acc0, acc1, x0, x1, after); break;
     }
 }
 
@@ -231,9 +236,13 @@ __device__ __forceinline__ void mfma_round(int n, const float *a0, const float *
 }
 
 // One scheduled job on the LDS-resident tile; `first`: its first MZ_WPF weight blocks and bias, loaded ahead.
+// `next`: receives the loads of the wave's following job (tile_wload's, issued here two behind every block that
+// multiplies and the rest behind the last: a compute unit's vector-memory path takes one 1 KB load per 16 cycles, and
+// eight waves that each issue eleven of them when a level begins stand 1.4 k cycles in front of their first matrix
+// instruction).
 template <int TM>
 __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, float *act, const TileSched &ts, int job,
-                                         int lane, const WReg &first)
+                                         int lane, const WReg &first, WReg &next)
 {
     const int w_off = sched_get(ts, 0, job), nkb = sched_get(ts, 1, job), mode = sched_get(ts, 2, job);
     const int in_off = sched_get(ts, 3, job), out_col = sched_get(ts, 4, job), skip_col = sched_get(ts, 5, job);
@@ -259,8 +268,29 @@ __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, 
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     const int n0 = nkb < MZ_WPF ? nkb : MZ_WPF;
     MZ_JSTAMP(0)
-    if (both) mfma_round<2>(n0, a0, a1, first.w, kb, acc0, acc1);
-    else mfma_round<1>(n0, a0, a1, first.w, kb, acc0, acc1);
+    {
+        const bool nreal = job + 1 < ts.n_jobs;
+        const int nj = nreal ? job + 1 : 0;
+        const int nw_off = sched_get(ts, 0, nj), nnkb = nreal ? sched_get(ts, 1, nj) : 0, nb_col = sched_get(ts, 7, nj);
+        const int nncols = nreal ? sched_get(ts, 8, nj) : 0;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(nb.wbase) + nw_off, 0, nnkb * 1024, 0x00020000);
+        const int boff = nncols > 0 ? (lane >> 4) * 16 : 0x7ffffff0;
+        auto ask = [&](auto I) {
+            constexpr int v = decltype(I)::value;
+            if constexpr (v < 100) {
+                if constexpr (2 * v < MZ_WPF) next.w[2 * v] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 2 * v * 1024, 0, 0));
+                if constexpr (2 * v + 1 < MZ_WPF) next.w[2 * v + 1] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (2 * v + 1) * 1024, 0, 0));
+            } else {
+                static_for<MZ_WPF>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    if constexpr (k >= 2 * (v - 100)) next.w[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + k * 1024, 0, 0));
+                });
+                next.bias = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.b, boff, nb_col * 4, 0));
+            }
+        };
+        if (both) mfma_round_hooked<2>(n0, a0, a1, first.w, kb, acc0, acc1, ask);
+        else mfma_round_hooked<1>(n0, a0, a1, first.w, kb, acc0, acc1, ask);
+    }
 #ifdef MZ_STAMPS
     if (acc0[0] == 12345.678f && acc1[3] == 1.0f) jt_++;   // the stamp waits for the results
 #endif
@@ -383,8 +413,7 @@ __device__ __forceinline__ void tile_run_levels(const MfmaNet &net, const NetBuf
         const int lend = __builtin_amdgcn_readlane(ts.lvl_end, l);
         for (; job < lend; job++) {
             WReg w1;
-            tile_wload(nb, ts, job + 1, lane, w1);
-            tile_job<TM>(net, nb, act, ts, job, lane, w0);
+            tile_job<TM>(net, nb, act, ts, job, lane, w0, w1);
             w0 = w1;
         }
 #ifdef MZ_STAMPS
@@ -686,14 +715,14 @@ __global__ __launch_bounds__(MZ_LVL_WAVES * 64) void k_net_level_rows(MfmaNet ne
     const float *a0 = tile + (lane & 15) * ts + (lane >> 4) * 4, *a1 = a0 + 16 * ts;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     // (blocks the wave does not have are addressed out of range: dropped by the hardware, zeros in the registers)
-    mfma_round_hooked(nkb < MZ_WPF ? nkb : MZ_WPF, a0, a1, wa, ka, acc0, acc1, [&](auto I) {
+    mfma_round_hooked<2>(nkb < MZ_WPF ? nkb : MZ_WPF, a0, a1, wa, ka, acc0, acc1, [&](auto I) {
         constexpr int k = decltype(I)::value + AHEAD;
         if constexpr (k < MZ_WPF) wa[k] = wload(k);
-        else if constexpr (KB > MZ_WPF) wb[k - MZ_WPF] = wload(k);
+        else if constexpr (KB > MZ_WPF && k < 100) wb[k - MZ_WPF] = wload(k);
     });
     if constexpr (KB > MZ_WPF) {
         if (nkb > MZ_WPF)
-            mfma_round_hooked((nkb < KB ? nkb : KB) - MZ_WPF, a0, a1, wb, kb, acc0, acc1, [&](auto I) {
+            mfma_round_hooked<2>((nkb < KB ? nkb : KB) - MZ_WPF, a0, a1, wb, kb, acc0, acc1, [&](auto I) {
                 constexpr int k = decltype(I)::value + AHEAD;
                 if constexpr (k < MZ_WPF) wb[k] = wload(MZ_WPF + k);
             });
