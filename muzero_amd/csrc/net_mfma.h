@@ -46,6 +46,9 @@ __device__ __forceinline__ float apply_act(float v, int act)
 // input and its biases are single 16-byte accesses per lane (with the operands the other way round a lane held one
 // column of four trees: four scattered 4-byte accesses each).
 #define MZ_WPF 10  // weight blocks fetched per round (k blocks of 16; a job with more runs in rounds of this)
+#ifndef MZ_TILE_ASK
+#define MZ_TILE_ASK 2  // weight blocks of the NEXT job that a tile-resident job asks for behind each of its own blocks
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Tile-resident evaluation (activations of the block's trees in LDS), software-pipelined per wave.
@@ -278,12 +281,14 @@ __device__ __forceinline__ void tile_job(const MfmaNet &net, const NetBufs &nb, 
         auto ask = [&](auto I) {
             constexpr int v = decltype(I)::value;
             if constexpr (v < 100) {
-                if constexpr (2 * v < MZ_WPF) next.w[2 * v] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + 2 * v * 1024, 0, 0));
-                if constexpr (2 * v + 1 < MZ_WPF) next.w[2 * v + 1] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (2 * v + 1) * 1024, 0, 0));
+                static_for<MZ_TILE_ASK>([&](auto J) {
+                    constexpr int k = MZ_TILE_ASK * v + decltype(J)::value;
+                    if constexpr (k < MZ_WPF) next.w[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + k * 1024, 0, 0));
+                });
             } else {
                 static_for<MZ_WPF>([&](auto K) {
                     constexpr int k = decltype(K)::value;
-                    if constexpr (k >= 2 * (v - 100)) next.w[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + k * 1024, 0, 0));
+                    if constexpr (k >= MZ_TILE_ASK * (v - 100)) next.w[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + k * 1024, 0, 0));
                 });
                 next.bias = as_float4(__builtin_amdgcn_raw_buffer_load_b128(nb.b, boff, nb_col * 4, 0));
             }
