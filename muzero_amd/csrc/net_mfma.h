@@ -1056,14 +1056,14 @@ __global__ __launch_bounds__(TM * 16) void k_search_mfma(Dev d, MfmaNet net, int
     for (int s = 0; s < n_sims; s++) {
         const int leaf = first_leaf + s;
         int parent = 0, action = 0, ntp = 0, depth = 0;
+        WReg wf;
+        tile_wload(nb, ts, 0, lane, wf);   // (the first job's weights depend on nothing a simulation does)
         if (live) {
             parent = descend<16, RL, GUMBEL>(d, dc, m, a, on, nz, noise_max_calls, calls, &action, &ntp, &depth);
             visited += depth + 1;
             tile_stage_inputs(net, row, hid + (long long)parent * H, action, a);
         }
         MZ_MSTAMP(st_a)
-        WReg wf;
-        tile_wload(nb, ts, 0, lane, wf);
         __syncthreads();
         MZ_MSTAMP(st_b)
         tile_run_levels<TM>(net, nb, act, ts, lane, wf);

@@ -463,6 +463,10 @@ __global__ __launch_bounds__(TM * 16, 2) void k_search_gcache(Dev d, MfmaNet net
         const int leaf = first_leaf + s;
         int parent = 0, action = 0, ntp = 0, depth = 0;
         BackupPre bp{0, 0, 0, 0, 0.0, 0.0};
+        // (the first job's weights depend on nothing a simulation does: asked for before the walk, they have arrived
+        // when the network begins)
+        WReg wf;
+        tile_wload(nb, ts, 0, lane, wf);
         MZ_XSTART()
         if (live) {
             // MCTS.simulate, mcts/mcts.py:98-114, over the decisions; all lanes of the group read the same words
@@ -485,8 +489,6 @@ __global__ __launch_bounds__(TM * 16, 2) void k_search_gcache(Dev d, MfmaNet net
             bp = backup_prefetch<16>(d, m, a, depth);   // the path's records travel while the network runs
         }
         MZ_MSTAMP(st_a)
-        WReg wf;
-        tile_wload(nb, ts, 0, lane, wf);
         lds_barrier();
         MZ_MSTAMP(st_b)
         // The work list of this simulation's re-decision phase, made while nothing waits for it: every group puts its
