@@ -384,10 +384,17 @@ __device__ __forceinline__ void tile_stage_inputs(const MfmaNet &net, float *row
     const int H = net.io[6], asz = net.io[8];
     if (net.plane_major) {   // lane = channel: no index arithmetic per element, consecutive lanes store consecutive floats
         const int C = net.io[10], P = H / C;
+        constexpr int NB = 9;   // a 3 x 3 board's cells in one batch of loads (the plain loop waits for memory every four)
         for (int ch = a; ch < C; ch += LANES) {
             const float *src = ph + ch * P;
             float *dst = row + net.io[0] + ch;
-            for (int cell = 0; cell < P; cell++) dst[cell * C] = src[cell];
+            for (int c0 = 0; c0 < P; c0 += NB) {
+                float v[NB];
+#pragma unroll
+                for (int u = 0; u < NB; u++) v[u] = src[c0 + u < P ? c0 + u : P - 1];
+#pragma unroll
+                for (int u = 0; u < NB; u++) if (c0 + u < P) dst[(c0 + u) * C] = v[u];
+            }
         }
     } else if ((H & 3) == 0) {
         const float4 *p4 = reinterpret_cast<const float4 *>(ph);
