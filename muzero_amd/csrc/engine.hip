@@ -1364,10 +1364,28 @@ static int upload_mfma(mz_ctx *c, const char *fn, const MfmaSlot &slot, const in
             }
         }
     }
-    // block descriptors of the level kernel: blocks of up to MZ_LVL_WAVES column tiles of one step, level by level
+    // Block descriptors of the level kernel, level by level: a block takes up to MZ_LVL_WAVES column tiles of one step.
+    // Workgroups go to the compute units in turn by their linear index (tree tile fast, block slow), the blocks of one
+    // tile to the units of one group of units/T (T tiles of trees, when T divides the units): blocks j and j + units/T
+    // of a level share a unit, and a level lasts as long as its most loaded unit.  Where a level has more blocks than
+    // such a group has units but not a multiple of them (13 on 8: five units hold 16 column tiles, three hold 8 or fewer)
+    // its steps are cut into the next multiple of blocks, as evenly as the steps allow, and ordered so that a heavy block
+    // shares its unit with a light one (16 blocks of 5..7 tiles: 13 per unit at most) - the matrix phase of such a
+    // level is as long as the most loaded unit's.
     std::vector<int32_t> desc;
     std::vector<int> job0(1, 0);
+    int n_cus = 256;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n_cus < 1) n_cus = 256;
+    }
+    const int n_tiles_max = (c->cfg.max_batch + 31) / 32;
+    const int groups = (n_tiles_max <= n_cus && n_cus % n_tiles_max == 0) ? n_cus / n_tiles_max : 1;
+    struct LvlJob { int32_t q[MZ_LVL_DESC]; long long cost; };
     for (int l = 0; l < n_levels; l++) {
+        std::vector<const int32_t *> lsteps;
+        int plain_jobs = 0;
         for (int s = 0; s < n_steps; s++) {
             const int32_t *st = steps_h + 12 * s;
             if (st[0] != l) continue;
@@ -1375,21 +1393,61 @@ static int upload_mfma(mz_ctx *c, const char *fn, const MfmaSlot &slot, const in
                 return fail(MZ_ERR_ARG, std::string(fn) + ": a first-level step reads outside the network inputs");
             if ((size_t)(st[2] * 16 + 4) * 32 * 4 > 160 * 1024)
                 return fail(MZ_ERR_ARG, std::string(fn) + ": a layer's inputs for 32 trees exceed LDS");
-            for (int ct = 0; ct < st[9]; ct += MZ_LVL_WAVES) {
-                const int n = std::min(MZ_LVL_WAVES, st[9] - ct);
+            lsteps.push_back(st);
+            plain_jobs += (st[9] + MZ_LVL_WAVES - 1) / MZ_LVL_WAVES;
+        }
+        // blocks per step: the plain count, or - see above - shares of the next multiple of the group's units
+        std::vector<int> njobs(lsteps.size());
+        for (size_t i = 0; i < lsteps.size(); i++) njobs[i] = (lsteps[i][9] + MZ_LVL_WAVES - 1) / MZ_LVL_WAVES;
+        const bool even_out = groups > 1 && plain_jobs > groups && plain_jobs % groups != 0 && !getenv("MZ_LVL_PLAIN");
+        if (even_out) {
+            const int target = (plain_jobs + groups - 1) / groups * groups;
+            long long tiles_total = 0;
+            for (const int32_t *st : lsteps) tiles_total += st[9];
+            int given = 0;
+            std::vector<double> rest(lsteps.size());
+            for (size_t i = 0; i < lsteps.size(); i++) {
+                const double share = (double)lsteps[i][9] * target / (double)tiles_total;
+                njobs[i] = std::max(njobs[i], std::max(1, (int)share));      // never fewer than the plain cut (8 tiles a block at most)
+                njobs[i] = std::min(njobs[i], (int)lsteps[i][9]);
+                rest[i] = share - njobs[i];
+                given += njobs[i];
+            }
+            while (given < target) {   // largest remainder first
+                size_t best = lsteps.size();
+                for (size_t i = 0; i < lsteps.size(); i++)
+                    if (njobs[i] < lsteps[i][9] && (best == lsteps.size() || rest[i] > rest[best])) best = i;
+                if (best == lsteps.size()) break;
+                njobs[best]++; rest[best] -= 1.0; given++;
+            }
+        }
+        std::vector<LvlJob> jobs;
+        for (size_t i = 0; i < lsteps.size(); i++) {
+            const int32_t *st = lsteps[i];
+            for (int k = 0; k < njobs[i]; k++) {
+                const int ct = (int)((long long)st[9] * k / njobs[i]), ct_end = (int)((long long)st[9] * (k + 1) / njobs[i]);
+                const int n = ct_end - ct;
+                if (n < 1 || n > MZ_LVL_WAVES) return fail(MZ_ERR_STATE, std::string(fn) + ": internal error (level block width)");
                 // everything a block needs, flattened: step fields + per-wave weight block lists
-                int32_t q[MZ_LVL_DESC] = {st[2] * 16, st[3], st[1], st[4], st[5], st[6], st[8], n, ct, 1};
+                LvlJob j{{st[2] * 16, st[3], st[1], st[4], st[5], st[6], st[8], n, ct, 1}, 0};
                 for (int w = 0; w < n; w++) {
                     if (st[10] + ct + w >= n_jobs) return fail(MZ_ERR_ARG, std::string(fn) + ": column tile table too short");
                     const int32_t *cj = ctinfo_h + 3 * (st[10] + ct + w);
                     if (cj[1] < 0 || cj[2] < 0 || cj[1] + cj[2] > n_kidx)
                         return fail(MZ_ERR_ARG, std::string(fn) + ": column tile reads outside the block index list");
-                    q[10 + 3 * w] = cj[0] * 4; q[11 + 3 * w] = cj[2]; q[12 + 3 * w] = cj[1];
-                    for (int i = 0; i < cj[2]; i++) if (kidx_h[cj[1] + i] != i) q[9] = 0;
+                    j.q[10 + 3 * w] = cj[0] * 4; j.q[11 + 3 * w] = cj[2]; j.q[12 + 3 * w] = cj[1];
+                    for (int i2 = 0; i2 < cj[2]; i2++) if (kidx_h[cj[1] + i2] != i2) j.q[9] = 0;
+                    j.cost += cj[2];
                 }
-                desc.insert(desc.end(), q, q + MZ_LVL_DESC);
+                jobs.push_back(j);
             }
         }
+        if (even_out) {   // heaviest first, row by row over the group's units, every other row backwards
+            std::stable_sort(jobs.begin(), jobs.end(), [](const LvlJob &x, const LvlJob &y) { return x.cost > y.cost; });
+            for (size_t r = 1; r * groups < jobs.size(); r += 2)
+                std::reverse(jobs.begin() + r * groups, jobs.begin() + std::min(jobs.size(), (r + 1) * groups));
+        }
+        for (const LvlJob &j : jobs) desc.insert(desc.end(), j.q, j.q + MZ_LVL_DESC);
         job0.push_back((int)(desc.size() / MZ_LVL_DESC));
     }
     for (int s2 = 0; s2 < n_steps; s2++)
