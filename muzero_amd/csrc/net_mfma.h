@@ -922,14 +922,26 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
     long long kst_ = clock64();
     const int slot_ = (threadIdx.x == 0 && blockIdx.x < 256) ? 512 + blockIdx.x : -1;
 #endif
-    const double *ct = stage_c_table<GUMBEL>(d, s_ct);
-    const double *sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
-    // searches too long for the sqrt(n / (1 + c)) table: its two factors, sqrt(n) and 1 / sqrt(1 + c), for the cached
-    // decisions (their product is within two units in the last place of the quotient's root)
-    bool sq_factors = false;
+    // The selection's tables (exploration constants, square-root factors) are not needed before the descent.  Where
+    // they are small - one entry per thread - and the long sqrt table is not in use, their values are only asked for here
+    // and go to LDS behind the backup, with one barrier: staged up front, their barriers held the epilogue back until
+    // the slowest wave's loads had arrived.  `late`: that form; every wave then stays until that barrier.
+    const double *ct = nullptr, *sqt = nullptr;
+    bool sq_factors = false, late = false;
+    double ct_pre = 0.0;
     if constexpr (!GUMBEL) {
+        const int n_sq = (d.L.S + 2) * (d.L.S + 1);
+        late = (select_next & 1) && d.L.S + 2 <= MZ_BLOCK && d.L.S + 2 <= MZ_CT_LDS && (!d.sqrt_table || n_sq > MZ_SQ_LDS);
+        if (late) {
+            if ((int)threadIdx.x < d.L.S + 2) ct_pre = d.c_table[threadIdx.x];
+        } else {
+            ct = stage_c_table<GUMBEL>(d, s_ct);
+            sqt = stage_sqrt_table<GUMBEL>(d, s_sq);
+        }
+        // searches too long for the sqrt(n / (1 + c)) table: its two factors, sqrt(n) and 1 / sqrt(1 + c), for the cached
+        // decisions (their product is within two units in the last place of the quotient's root)
         sq_factors = (select_next & 3) == 3 && d.dec != nullptr && sqt == nullptr && 2 * (d.L.S + 2) <= MZ_SQ_LDS;
-        if (sq_factors) {
+        if (sq_factors && !late) {
             for (int i = threadIdx.x; i < d.L.S + 2; i += MZ_BLOCK) {
                 s_sq[i] = sqrt((double)i);
                 s_sq[d.L.S + 2 + i] = 1.0 / sqrt((double)(1 + i));
@@ -937,10 +949,25 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
             __syncthreads();
         }
     }
-    if (t >= t_end) return;
+    auto stage_late = [&]() {   // every thread of the block, once
+        if ((int)threadIdx.x < d.L.S + 2) {
+            s_ct[threadIdx.x] = ct_pre;
+            if (sq_factors) {
+                s_sq[threadIdx.x] = sqrt((double)threadIdx.x);
+                s_sq[d.L.S + 2 + threadIdx.x] = 1.0 / sqrt((double)(1 + threadIdx.x));
+            }
+        }
+        __syncthreads();
+        ct = s_ct;
+    };
+    if (t >= t_end) {
+        if (late) stage_late();
+        return;
+    }
     MZ_SSTAMP(slot_, 0)
     if (depth < 1 || depth > d.L.S || parent < 0 || parent >= leaf) {
         if (a == 0) atomicExch(d.err, 1);
+        if (late) stage_late();
         return;
     }
     const TreeMem m = tree_mem(d, t);
@@ -960,6 +987,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void k_leaf_backup_select(Dev d, MfmaNet 
         return;
     }
     __threadfence_block();
+    if (late) stage_late();
     MZ_SSTAMP(slot_, 2)
     const double *nz = noise ? noise + (long long)t * noise_max_calls * d.L.A : nullptr;
     DescendCtx dc = descend_ctx<GUMBEL>(d, t, a, on, ct, sqt);
