@@ -111,3 +111,23 @@ def test_cached_puct_at_the_benchmark_size(monkeypatch):
     ref = _search(monkeypatch, WIDE, False, 1024, 200, cached=False)
     got = _search(monkeypatch, WIDE, False, 1024, 200, cached=True)
     _same(got, ref)
+
+
+def test_cached_puct_in_a_search_longer_than_a_block_has_threads(monkeypatch):
+    """More simulations than the tree kernel's block has threads: the exploration constants are staged up front by
+    strided loops instead of one entry per thread behind the backup, and the square-root factors replace the table."""
+    ref = _search(monkeypatch, ODD, True, 48, 300, cached=False)
+    got = _search(monkeypatch, ODD, True, 48, 300, cached=True)
+    assert ref[1].max() > 255
+    _same(got, ref)
+
+
+def test_level_blocks_evened_out_over_the_compute_units_give_the_same_trees(monkeypatch):
+    """Where a network level has more blocks per tile than the tile's group of compute units, but not a multiple of it,
+    its steps are cut into more, smaller blocks (MZ_LVL_PLAIN=1: the plain cut of 8 column tiles per block).  An
+    output's products are summed in the same order either way: the trees must not differ in a single bit."""
+    monkeypatch.setenv('MZ_LVL_PLAIN', '1')
+    ref = _search(monkeypatch, WIDE, False, 1024, 40, cached=True)
+    monkeypatch.delenv('MZ_LVL_PLAIN')
+    got = _search(monkeypatch, WIDE, False, 1024, 40, cached=True)
+    _same(got, ref)
