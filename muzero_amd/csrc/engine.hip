@@ -1368,10 +1368,12 @@ static int upload_mfma(mz_ctx *c, const char *fn, const MfmaSlot &slot, const in
     // Workgroups go to the compute units in turn by their linear index (tree tile fast, block slow), the blocks of one
     // tile to the units of one group of units/T (T tiles of trees, when T divides the units): blocks j and j + units/T
     // of a level share a unit, and a level lasts as long as its most loaded unit.  Where a level has more blocks than
-    // such a group has units but not a multiple of them (13 on 8: five units hold 16 column tiles, three hold 8 or fewer)
-    // its steps are cut into the next multiple of blocks, as evenly as the steps allow, and ordered so that a heavy block
+    // such a group has units but fewer than twice as many (13 on 8: five units hold 16 column tiles, three hold 8 or
+    // fewer) its steps are cut into two blocks a unit, as evenly as the steps allow, and ordered so that a heavy block
     // shares its unit with a light one (16 blocks of 5..7 tiles: 13 per unit at most) - the matrix phase of such a
-    // level is as long as the most loaded unit's.
+    // level is as long as the most loaded unit's.  With more than two blocks a unit the plain cut stays: every further
+    // block copies its tile's inputs once more, and that was measured to cost more than the evening-out returns
+    // (13 blocks on 4 units cut into 16: 2.5 % slower; on 2 units into 14: 0.6 %).
     std::vector<int32_t> desc;
     std::vector<int> job0(1, 0);
     int n_cus = 256;
@@ -1396,12 +1398,12 @@ static int upload_mfma(mz_ctx *c, const char *fn, const MfmaSlot &slot, const in
             lsteps.push_back(st);
             plain_jobs += (st[9] + MZ_LVL_WAVES - 1) / MZ_LVL_WAVES;
         }
-        // blocks per step: the plain count, or - see above - shares of the next multiple of the group's units
+        // blocks per step: the plain count, or - see above - shares of two blocks for each of the group's units
         std::vector<int> njobs(lsteps.size());
         for (size_t i = 0; i < lsteps.size(); i++) njobs[i] = (lsteps[i][9] + MZ_LVL_WAVES - 1) / MZ_LVL_WAVES;
-        const bool even_out = groups > 1 && plain_jobs > groups && plain_jobs % groups != 0 && !getenv("MZ_LVL_PLAIN");
+        const bool even_out = groups > 1 && plain_jobs > groups && plain_jobs < 2 * groups && !getenv("MZ_LVL_PLAIN");
         if (even_out) {
-            const int target = (plain_jobs + groups - 1) / groups * groups;
+            const int target = 2 * groups;
             long long tiles_total = 0;
             for (const int32_t *st : lsteps) tiles_total += st[9];
             int given = 0;
