@@ -8,7 +8,12 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include <map>
@@ -185,22 +190,143 @@ extern "C" int mz_legacy_root_noise(uint32_t *mt_key, int32_t *mt_pos, double al
 // loc 0, scale 1): u = 1 - next_double(), value = -log(-log(u)), one uniform per value in order.  The uniforms come off
 // the Mersenne Twister one after the other; the two logarithms per value - nearly all of the time - are taken by a few
 // host threads side by side, each with the C library's log on its own stretch, so every value has the bits NumPy gives.
+// Helper threads of the host-side draws, kept for the life of the process: starting sixteen threads costs as much as
+// the draws of a 16 384-tree batch themselves.  start() hands fn(w) to helpers w = 0 .. n - 1 and returns, wait() returns
+// when all of them have; one job at a time (`call`, held by the caller from start() to wait()).  A process forked from
+// one that owns a pool has none of its threads: the pool is then made again (host_pool()).
+class HostPool {
+public:
+    explicit HostPool(int n)
+    {
+        for (int w = 0; w < n; w++) threads_.emplace_back([this, w]() { work(w); });
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_work_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    void start(int n, std::function<void(int)> fn)
+    {
+        { std::lock_guard<std::mutex> lk(m_); job_ = std::move(fn); active_ = std::min(n, size()); pending_ = active_; epoch_++; }
+        cv_work_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [this]() { return pending_ == 0; });
+    }
+    std::mutex call;
+private:
+    void work(int w)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        unsigned long long seen = 0;
+        for (;;) {
+            cv_work_.wait(lk, [&]() { return stop_ || epoch_ != seen; });
+            if (stop_) return;
+            seen = epoch_;
+            if (w >= active_) continue;
+            lk.unlock();
+            job_(w);
+            lk.lock();
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::function<void(int)> job_;
+    unsigned long long epoch_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+static HostPool &host_pool(int n_threads)
+{
+    static std::mutex m;
+    static std::unique_ptr<HostPool> pool;
+    static pid_t owner = 0;
+    std::lock_guard<std::mutex> lk(m);
+    if (pool && owner != getpid()) (void)pool.release();   // a forked child: the threads stayed with the parent
+    if (!pool || pool->size() < n_threads) {
+        pool.reset();                                        // (joins the smaller pool's idle threads)
+        pool.reset(new HostPool(n_threads));
+        owner = getpid();
+    }
+    return *pool;
+}
+
+// The next n doubles of the stream (random_double: 27 + 26 bits of two consecutive words), each as 1 - u, in bulk: the words
+// of a block are tempered in one loop and paired in another - both loops without a branch, unlike a call per value that
+// asks "block used up?" twice - and `progress` (may be null) is told how many values stand in `out` after every block.
+static void legacy_one_minus_doubles(LegacyMT &mt, double *out, int64_t n, std::atomic<int64_t> *progress)
+{
+    uint32_t tw[624];
+    uint32_t first = 0;
+    bool have_first = false;
+    int64_t i = 0;
+    while (i < n) {
+        if (mt.pos == 624) mt.refill();
+        const int64_t need = 2 * (n - i) - (have_first ? 1 : 0);
+        const int take = (int)std::min<int64_t>(624 - mt.pos, need);
+        const uint32_t *src = mt.key + mt.pos;
+        for (int k = 0; k < take; k++) {
+            uint32_t y = src[k];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            tw[k] = y;
+        }
+        mt.pos += take;
+        auto value = [](uint32_t a, uint32_t b) {
+            return 1.0 - ((double)(int32_t)(a >> 5) * 67108864.0 + (double)(int32_t)(b >> 6)) / 9007199254740992.0;
+        };
+        int k = 0;
+        if (have_first) { out[i++] = value(first, tw[0]); k = 1; have_first = false; }
+        const int pairs = (take - k) / 2;
+        for (int j = 0; j < pairs; j++) out[i + j] = value(tw[k + 2 * j], tw[k + 2 * j + 1]);
+        i += pairs;
+        k += 2 * pairs;
+        if (k < take) { first = tw[k]; have_first = true; }
+        if (progress) progress->store(i, std::memory_order_release);
+    }
+}
+
 extern "C" int mz_legacy_gumbel(uint32_t *mt_key, int32_t *mt_pos, int64_t n, double *out)
 {
     if (!mt_key || !mt_pos || n < 0 || (n > 0 && !out) || *mt_pos < 0 || *mt_pos > 624)
         return fail(MZ_ERR_ARG, "mz_legacy_gumbel: bad argument");
     LegacyMT mt{mt_key, *mt_pos};
-    for (int64_t i = 0; i < n; i++) out[i] = 1.0 - mt.next_double();
-    *mt_pos = mt.pos;
-    auto transform = [out](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) out[i] = -log(-log(out[i])); };
+    // The generator is serial, the logarithms are not: helper threads take them chunk by chunk behind the generator
+    // (a chunk is theirs once `progress` has passed its end), so that little more than the generator's time is left.
+    constexpr int64_t CHUNK = 4096;
     unsigned hw = std::thread::hardware_concurrency();
     int64_t n_threads = std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), n / 8192);   // a thread per 8192 values at least
     if (const char *e = getenv("MZ_HOST_THREADS")) n_threads = std::min<int64_t>(n_threads, std::max(1, atoi(e)));
-    if (n_threads <= 1) { transform(0, n); return MZ_OK; }
-    std::vector<std::thread> pool;
-    for (int64_t k = 1; k < n_threads; k++) pool.emplace_back(transform, n * k / n_threads, n * (k + 1) / n_threads);
-    transform(0, n / n_threads);
-    for (std::thread &t : pool) t.join();
+    auto transform = [out](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) out[i] = -log(-log(out[i])); };
+    if (n_threads <= 1) {
+        legacy_one_minus_doubles(mt, out, n, nullptr);
+        *mt_pos = mt.pos;
+        transform(0, n);
+        return MZ_OK;
+    }
+    std::atomic<int64_t> progress{0};
+    const int64_t n_chunks = (n + CHUNK - 1) / CHUNK, n_helpers = n_threads - 1;
+    HostPool &pool = host_pool((int)n_helpers);
+    std::lock_guard<std::mutex> one_job(pool.call);
+    pool.start((int)n_helpers, [&](int w) {
+        for (int64_t c = w; c < n_chunks; c += n_helpers) {
+            const int64_t lo = c * CHUNK, hi = std::min(n, lo + CHUNK);
+            while (progress.load(std::memory_order_acquire) < hi) std::this_thread::yield();
+            transform(lo, hi);
+        }
+    });
+    legacy_one_minus_doubles(mt, out, n, &progress);   // ends with progress = n: every helper comes to its end
+    *mt_pos = mt.pos;
+    pool.wait();
     return MZ_OK;
 }
 

@@ -87,3 +87,54 @@ def test_native_gumbel_small_draws_and_shapes():
     got = engine.legacy_gumbel((4096, 9))
     assert got.shape == (4096, 9)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('words_before', [1, 623, 624])
+def test_native_gumbel_from_odd_positions_and_block_ends(words_before):
+    """A value is made of two consecutive words of the generator: from an odd position inside a block the pairs straddle
+    the block boundaries, and a block that ends behind a value's first word hands that word over to the next one."""
+    np.random.seed(3)
+    for _ in range(words_before):
+        np.random.bytes(4)            # one word each
+    state = np.random.get_state()
+    want = np.random.gumbel(size=20001)
+    after = np.random.random_sample(3)
+    np.random.set_state(state)
+    got = engine.legacy_gumbel((20001,))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(np.random.random_sample(3), after)
+
+
+def test_native_gumbel_in_a_forked_child_and_from_several_threads():
+    """The helper threads of the draws live as long as the process; a forked child has none of them and must get its
+    own, and callers on several threads take turns."""
+    import os, threading
+    np.random.seed(1)
+    state = np.random.get_state()
+    want = np.random.gumbel(size=(16384, 9))
+    np.random.set_state(state)
+    np.testing.assert_array_equal(engine.legacy_gumbel((16384, 9)), want)
+    pid = os.fork()
+    if pid == 0:
+        code = 3
+        try:
+            np.random.set_state(state)
+            code = 0 if (engine.legacy_gumbel((16384, 9)) == want).all() else 4
+        finally:
+            os._exit(code)
+    assert os.WEXITSTATUS(os.waitpid(pid, 0)[1]) == 0
+    import ctypes as C
+    results = []
+
+    def call():
+        key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+        pos, out = C.c_int32(int(state[2])), np.empty(16384 * 9)
+        rc = engine.lib().mz_legacy_gumbel(key.ctypes.data_as(C.c_void_p), C.byref(pos), C.c_int64(out.size),
+                                           out.ctypes.data_as(C.c_void_p))
+        results.append(rc == 0 and (out.reshape(16384, 9) == want).all())
+    threads = [threading.Thread(target=call) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert results == [True] * 4
