@@ -243,16 +243,16 @@ private:
     bool stop_ = false;
 };
 
-static HostPool &host_pool(int n_threads)
+static HostPool &host_pool()
 {
     static std::mutex m;
     static std::unique_ptr<HostPool> pool;
     static pid_t owner = 0;
     std::lock_guard<std::mutex> lk(m);
     if (pool && owner != getpid()) (void)pool.release();   // a forked child: the threads stayed with the parent
-    if (!pool || pool->size() < n_threads) {
-        pool.reset();                                        // (joins the smaller pool's idle threads)
-        pool.reset(new HostPool(n_threads));
+    if (!pool) {   // of one size for good: a caller may be inside a job while another asks for the pool
+        const unsigned hw = std::thread::hardware_concurrency();
+        pool.reset(new HostPool(std::max(1, (int)std::min<unsigned>(hw ? hw : 1u, 16u) - 1)));
         owner = getpid();
     }
     return *pool;
@@ -314,8 +314,8 @@ extern "C" int mz_legacy_gumbel(uint32_t *mt_key, int32_t *mt_pos, int64_t n, do
         return MZ_OK;
     }
     std::atomic<int64_t> progress{0};
-    const int64_t n_chunks = (n + CHUNK - 1) / CHUNK, n_helpers = n_threads - 1;
-    HostPool &pool = host_pool((int)n_helpers);
+    HostPool &pool = host_pool();
+    const int64_t n_chunks = (n + CHUNK - 1) / CHUNK, n_helpers = std::min<int64_t>(n_threads - 1, pool.size());
     std::lock_guard<std::mutex> one_job(pool.call);
     pool.start((int)n_helpers, [&](int w) {
         for (int64_t c = w; c < n_chunks; c += n_helpers) {
