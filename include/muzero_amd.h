@@ -404,9 +404,7 @@ int mz_legacy_root_noise(uint32_t *mt_key, int32_t *mt_pos, double alpha, int32_
 
 /* np.random.gumbel(size=n) of the same legacy generator - the draw of gumbel_noise in MCTS.search (mcts/mcts.py:211),
  * for n = B * n_actions the draws of B consecutive searches: out f64[n] = -log(-log(1 - next_double())) in stream
- * order; state in and out as for mz_legacy_root_noise.  Host only.  Draws of 16 384 values and more take their
- * logarithms on helper threads (at most 15, fewer with MZ_HOST_THREADS=k) that are started at the first such call and
- * kept until the process ends; a forked child starts its own; concurrent callers take turns. */
+ * order; state in and out as for mz_legacy_root_noise.  Host only; the logarithms run on a few host threads. */
 int mz_legacy_gumbel(uint32_t *mt_key, int32_t *mt_pos, int64_t n, double *out);
 
 /* Library/ABI version. */
